@@ -1,0 +1,176 @@
+/*
+ * mrs.h -- C ABI of the MI355X (gfx950) Morton-key radix sort.
+ *
+ * This is the boundary a host program binds (Rust `extern "C"`, ctypes, cgo ...)
+ * in place of the reference's wgpu compute path.  The reference has exactly one
+ * entry point for that path,
+ *
+ *     pub fn run_compute_shaders(device, encoder) -> Vec<Buffer>   src/main.rs:376
+ *
+ * which records one Morton-encode dispatch and NUM_PASSES x {histogram, prefix
+ * sum, scatter} dispatches into a command encoder that the caller submits.
+ * The functions below are that recording split into its parts.  Like the
+ * recording, every function only ENQUEUES work on the caller's HIP stream and
+ * never synchronises with the host; unlike wgpu (which panics through
+ * on_uncaptured_error, src/main.rs:711-717) errors come back as a negative
+ * status and a message from mrs_last_error_string().
+ *
+ * Conventions
+ *   - all pointers named *_dev / keys* / vals* are DEVICE pointers owned by the
+ *     caller; the library never frees or reallocates them;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - the device of the context must be the calling thread's current device;
+ *   - a plan may be used by one host thread and one stream at a time; distinct
+ *     plans are independent.
+ */
+#ifndef MRS_H
+#define MRS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRS_VERSION_MAJOR 0
+#define MRS_VERSION_MINOR 1
+
+/* status codes */
+#define MRS_OK 0
+#define MRS_ERR_INVALID_ARGUMENT (-1)
+#define MRS_ERR_HIP (-2)
+#define MRS_ERR_UNSUPPORTED (-3)
+#define MRS_ERR_OUT_OF_MEMORY (-4)
+#define MRS_ERR_DEVICE_TIMEOUT (-5)
+
+/* pass algorithm */
+#define MRS_ALGO_THREE_KERNEL 0 /* histogram -> prefix sum -> scatter, as src/main.rs:594-665 */
+#define MRS_ALGO_ONESWEEP 1     /* one histogram kernel + one chained-scan kernel per digit   */
+
+/* byte sizes of the reference buffer elements */
+#define MRS_MORTON_UNIFORMS_BYTES 51248 /* MortonCodeConstants, morton_code.wgsl:19-26 */
+#define MRS_VERTEX_STRIDE 48            /* Vertex, morton_code.wgsl:1-9, src/types.rs:12-17 */
+#define MRS_TRIANGLE_STRIDE 16          /* TriangleIndices, src/types.rs:30-36            */
+
+typedef struct mrs_context mrs_context;
+typedef struct mrs_plan mrs_plan;
+
+/* Replaces the compile-time constants of src/constants.rs:1-21 and the buffer
+ * sizing of create_all_buffers / create_prefix_buffers (src/main.rs:31-85,
+ * 236-253). */
+typedef struct mrs_plan_desc {
+    uint64_t n;            /* capacity in elements (NUM_TRIANGLES); 0 < n < 2^32             */
+    int32_t key_words;     /* 1: u32 key.  2: u64 key stored (lo, hi), src/main.rs:60-61   */
+    int32_t payload_bytes; /* 0, 4 (u32 index) or 16 (TriangleIndices)                      */
+    int32_t digit_bits;    /* BITS_PER_PASS: 4 or 8                                         */
+    int32_t begin_bit;     /* first key bit sorted on (0)                                   */
+    int32_t end_bit;       /* one past the last key bit (32*key_words = NUM_PASSES*8 bits)  */
+    int32_t algo;          /* MRS_ALGO_*                                                    */
+    int32_t tile_items;    /* keys per workgroup; 0 = tuned default.  256 with
+                              MRS_ALGO_THREE_KERNEL gives the reference's histogram
+                              layout [256][ceil(n/256)] exactly                             */
+} mrs_plan_desc;
+
+/* Sizes a plan reports (mrs_plan_get_info). */
+typedef struct mrs_plan_info {
+    uint32_t num_passes;     /* NUM_PASSES                                                  */
+    uint32_t radix;          /* HISTOGRAM_SIZE = 1 << digit_bits                            */
+    uint32_t tile_items;     /* resolved keys per workgroup                                 */
+    uint32_t threads;        /* workgroup size                                              */
+    uint64_t max_tiles;      /* ceil(n / tile_items) = number_of_workgroups                 */
+    uint64_t histogram_len;  /* u32 entries of the block histogram (three-kernel), radix*W  */
+    uint64_t temp_bytes;     /* device bytes the plan owns                                  */
+} mrs_plan_info;
+
+/* ---- library ------------------------------------------------------------ */
+/* Message of the calling thread's last failing call ("" if none). */
+const char* mrs_last_error_string(void);
+/* MRS_VERSION_MAJOR << 16 | MRS_VERSION_MINOR */
+int mrs_version(void);
+
+/* ---- context: replaces Instance/adapter/device acquisition, src/main.rs:692-707 */
+int mrs_context_create(int device_id, mrs_context** out);
+int mrs_context_destroy(mrs_context* ctx);
+
+/* ---- plan: replaces create_all_buffers' temporaries (histogram + prefix_sums,
+ * src/main.rs:45-51,236-253) and the per-pass uniform buffers (src/main.rs:361-374) */
+int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* desc, mrs_plan** out);
+int mrs_plan_destroy(mrs_plan* plan);
+int mrs_plan_get_info(const mrs_plan* plan, mrs_plan_info* info);
+/* Synchronises `stream` and reports MRS_ERR_DEVICE_TIMEOUT if a chained-scan
+ * kernel gave up waiting for a predecessor tile since the last check.  For
+ * tests and harnesses; not needed on the hot path. */
+int mrs_plan_check(mrs_plan* plan, void* stream);
+
+/* ---- Morton encode ------------------------------------------------------- */
+/* Replaces the "Morton Coding" dispatch of morton_code_unrolled
+ * (src/main.rs:581-592, src/shaders/morton_code.wgsl:90-335).  Buffers have the
+ * reference's byte layouts: `uniforms_dev` = MortonCodeConstants blob
+ * (MRS_MORTON_UNIFORMS_BYTES), `vertices_dev` stride 48 B with position at byte
+ * 0, `triangles_dev` stride 16 B; writes codes_dev[2t] = lo, [2t+1] = hi. */
+int mrs_morton_encode_lut(mrs_context* ctx, const void* uniforms_dev,
+                          const void* vertices_dev, uint64_t num_vertices,
+                          const void* triangles_dev, uint64_t n,
+                          uint32_t* codes_dev, void* stream);
+/* 30-bit Morton key of a point cloud (xyz f32, 12 B per point), payload = the
+ * point's index.  No counterpart in the reference: this is the key shape the
+ * throughput metric is quoted on.  mn/mx are HOST pointers to 3 floats (the
+ * scene bounds, as create_scene computes them on the CPU, src/main.rs:148-154). */
+int mrs_morton_encode30(mrs_context* ctx, const float* xyz_dev, uint64_t n,
+                        const float* mn, const float* mx, uint32_t* keys_dev,
+                        uint32_t* idx_dev, void* stream);
+
+/* ---- the sort ------------------------------------------------------------- */
+/* Replaces the NUM_PASSES loop of src/main.rs:594-665 with its ping-pong bind
+ * groups (src/main.rs:515-576): pass 0 reads (keys_a, vals_a) and writes
+ * (keys_b, vals_b), pass 1 the other way round, and so on.  *result_in_b is set
+ * (on the host, immediately) to 1 when the sorted data ends in the B buffers,
+ * i.e. when the number of passes is odd (src/main.rs:819-823).  n <= plan n.
+ * vals_* may be NULL when payload_bytes == 0. */
+int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a,
+                   void* keys_b, void* vals_b, void* stream, int* result_in_b);
+
+/* ---- single stages of one pass (MRS_ALGO_THREE_KERNEL plans) --------------- */
+/* radix_sort_compute_histogram (src/shaders/radix_sort_histogram.wgsl:42-60):
+ * hist_dev[W*d + b] = number of keys of block b whose digit `pass` equals d. */
+int mrs_histogram(mrs_plan* plan, uint64_t n, const void* keys_dev, uint32_t pass,
+                  uint32_t* hist_dev, void* stream);
+/* The whole prefix-sum stage (radix_sort_block_sum_large / _small / _after,
+ * src/main.rs:604-655): in-place exclusive scan of hist_dev[0 .. radix*W). */
+int mrs_scan(mrs_plan* plan, uint64_t n, uint32_t* hist_dev, void* stream);
+/* radix_sort_index (src/shaders/radix_sort_index.wgsl:255-308): stable scatter
+ * by digit `pass` using the scanned histogram. */
+int mrs_scatter(mrs_plan* plan, uint64_t n, const void* keys_in, const void* vals_in,
+                void* keys_out, void* vals_out, const uint32_t* scanned_hist_dev,
+                uint32_t pass, void* stream);
+
+/* ---- multi-GPU building blocks (sort sharded by top-digit bucket) ---------- */
+/* counts_dev[b] (u64, 1 << bits entries) = number of keys whose bits
+ * [shift, shift+bits) equal b.  Input to the all-reduce of the global digit
+ * histogram. */
+int mrs_bucket_histogram(mrs_context* ctx, const void* keys_dev, uint64_t n,
+                         int32_t key_words, uint32_t shift, uint32_t bits,
+                         uint64_t* counts_dev, void* stream);
+/* Stable partition of (key, payload) pairs into `num_parts` <= 16 contiguous
+ * groups: an element goes to group map_dev[(key >> shift) & ((1<<bits)-1)]
+ * (u8 table, 1 << bits entries).  Uses the plan's onesweep machinery (the plan
+ * must be MRS_ALGO_ONESWEEP).  part_counts_dev (u32[16], may be NULL) receives
+ * the group sizes. */
+int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, const void* vals_in,
+                  void* keys_out, void* vals_out, uint32_t shift, uint32_t bits,
+                  const uint8_t* map_dev, uint32_t num_parts,
+                  uint32_t* part_counts_dev, void* stream);
+
+/* ---- input generator (stands in for create_scene's RNG, src/main.rs:114-161) */
+/* xyz_dev[3i+c] = top 24 bits of hash(seed, c, i) * 2^-24, uniform in [0,1). */
+int mrs_generate_points(mrs_context* ctx, uint64_t seed, uint64_t n, float* xyz_dev,
+                        void* stream);
+/* out_dev[i] = hash(seed, stream_id, i), a uniform u32. */
+int mrs_generate_u32(mrs_context* ctx, uint64_t seed, uint64_t stream_id, uint64_t n,
+                     uint32_t* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRS_H */

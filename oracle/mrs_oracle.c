@@ -1,0 +1,547 @@
+/*
+ * CPU oracle for the Morton-encode + LSD radix sort path -- see mrs_oracle.h.
+ *
+ * TEST INFRASTRUCTURE ONLY: a plain-C restatement of the reference algorithm.
+ * Build with -ffp-contract=off (the Makefile does) so that the f32 arithmetic
+ * of the Morton encoders is evaluated operation by operation.
+ *
+ * Citations are file:line of the reference repository.
+ */
+#include "mrs_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* host helpers: src/utilities.rs:10-55                                       */
+/* ------------------------------------------------------------------------- */
+uint64_t orc_div_ceil(uint64_t l, uint64_t r) { return (l + r - 1) / r; }
+
+uint64_t orc_num_workgroups(uint64_t element_count, uint64_t workgroup_size)
+{
+    return orc_div_ceil(element_count, workgroup_size);
+}
+
+uint64_t orc_round_up(uint64_t l, uint64_t r)
+{
+    uint64_t rem = l % r;
+    return rem == 0 ? l : l + r - rem;
+}
+
+/* src/main.rs:201-233 with the shipped constants (src/constants.rs:7-17):
+ * ITEMS_PER_HISTOGRAM_PASS = 256, HISTOGRAM_SIZE = 256,
+ * ITEMS_PER_LARGE_PREFIX = 256, MAX_ITEMS_IN_SMALL_PREFIX = 1024. */
+int orc_prefix_buffer_sizes(uint64_t num_elements, uint64_t* out, int cap)
+{
+    int levels = 0;
+    uint64_t items = orc_num_workgroups(num_elements, 256) * 256;
+    items = orc_round_up(items, 256);
+    if (items <= 1024) return 0;
+    items /= 256;
+    items = orc_round_up(items, 256);
+    while (items > 1024) {
+        if (levels < cap) out[levels] = items;
+        levels++;
+        items /= 256;
+        items = orc_round_up(items, 256);
+    }
+    if (levels < cap) out[levels] = items;
+    levels++;
+    return levels;
+}
+
+/* ------------------------------------------------------------------------- */
+/* digit selection                                                            */
+/* ------------------------------------------------------------------------- */
+/* radix_sort_histogram.wgsl:28-36; src/tests.rs:17-24 */
+uint32_t orc_select_digit8(uint32_t pass_number, uint32_t lo, uint32_t hi)
+{
+    if (pass_number < 4u) return (lo >> (pass_number * 8u)) & 255u;
+    return (hi >> ((pass_number - 4u) * 8u)) & 255u;
+}
+
+/* src/tests.rs:7-15 */
+uint32_t orc_select_digit6(uint32_t pass_number, uint32_t lo, uint32_t hi)
+{
+    if (pass_number <= 4u) return (lo >> (pass_number * 6u)) & 63u;
+    if (pass_number == 5u) return ((lo >> 30) & 3u) | ((hi & 15u) << 2);
+    return (hi >> ((pass_number - 6u) * 6u + 4u)) & 63u;
+}
+
+uint32_t orc_digit(const uint32_t* key, int key_words, uint32_t shift, uint32_t bits)
+{
+    uint64_t v = key[0];
+    if (key_words == 2) v |= (uint64_t)key[1] << 32;
+    uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+    return (uint32_t)((v >> shift) & mask);
+}
+
+/* src/main.rs:1042-1051 */
+uint64_t orc_select_bits(uint64_t value, uint32_t i)
+{
+    if (i >= 8) return value;
+    return value & ((1ull << (i * 8u)) - 1ull);
+}
+
+/* ------------------------------------------------------------------------- */
+/* one pass                                                                   */
+/* ------------------------------------------------------------------------- */
+/* radix_sort_histogram.wgsl:42-60: block b counts its `tile` keys, thread d
+ * stores bin d at hist[num_workgroups*d + b]. */
+void orc_block_histogram(const uint32_t* keys, uint64_t n, int key_words,
+                         uint32_t shift, uint32_t bits, uint32_t tile,
+                         uint32_t* hist)
+{
+    uint64_t W = orc_div_ceil(n, tile);
+    uint64_t radix = 1ull << bits;
+    memset(hist, 0, (size_t)(radix * W) * sizeof(uint32_t));
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t d = orc_digit(keys + i * (uint64_t)key_words, key_words, shift, bits);
+        hist[W * d + i / tile] += 1u;
+    }
+}
+
+/* src/main.rs:933-946: running sum, value replaced by the sum before it. */
+void orc_exclusive_scan(uint32_t* vals, uint64_t len)
+{
+    uint32_t sum = 0;
+    for (uint64_t i = 0; i < len; ++i) {
+        uint32_t g = vals[i];
+        vals[i] = sum;
+        sum += g;
+    }
+}
+
+/* radix_sort_block_sum_large.wgsl:146-160: per 256-chunk exclusive scan, chunk
+ * total to block_sums[chunk]. */
+static void scan_large_up(uint32_t* vals, uint64_t nchunks, uint32_t* block_sums)
+{
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        uint32_t sum = 0;
+        for (uint32_t t = 0; t < 256; ++t) {
+            uint32_t g = vals[c * 256 + t];
+            vals[c * 256 + t] = sum;
+            sum += g;
+        }
+        block_sums[c] = sum;
+    }
+}
+
+/* radix_sort_block_sum_small.wgsl:50-77: up to four 256-chunks, the running
+ * total m_k carried into the next chunk. */
+static void scan_small(uint32_t* vals, uint64_t len)
+{
+    uint32_t carry = 0;
+    for (uint64_t c = 0; c * 256 < len && c < 4; ++c) {
+        uint32_t sum = 0;
+        for (uint32_t t = 0; t < 256; ++t) {
+            uint32_t g = vals[c * 256 + t];
+            vals[c * 256 + t] = sum + carry;
+            sum += g;
+        }
+        carry += sum;
+    }
+}
+
+/* radix_sort_block_sum_large.wgsl:162-172 */
+static void scan_large_down(uint32_t* vals, uint64_t len, const uint32_t* block_sums)
+{
+    for (uint64_t i = 0; i < len; ++i) vals[i] += block_sums[i / 256];
+}
+
+/* Dispatch order of src/main.rs:604-655.  Level sizes follow
+ * src/main.rs:201-233 applied to a histogram of `len` entries. */
+void orc_hierarchical_scan(uint32_t* vals, uint64_t len)
+{
+    uint64_t sizes[8];
+    int levels = 0;
+    if (len > 1024) {
+        uint64_t items = orc_round_up(len / 256, 256);
+        while (items > 1024) {
+            sizes[levels++] = items;
+            items = orc_round_up(items / 256, 256);
+        }
+        sizes[levels++] = items;
+    }
+    if (levels == 0) {
+        scan_small(vals, len);
+        return;
+    }
+    uint32_t* bufs[8];
+    for (int i = 0; i < levels; ++i)
+        bufs[i] = (uint32_t*)calloc((size_t)sizes[i], sizeof(uint32_t));
+    /* "Large Prefix Sum part 1" */
+    scan_large_up(vals, len / 256, bufs[0]);
+    for (int i = 1; i < levels; ++i)
+        scan_large_up(bufs[i - 1], orc_div_ceil(sizes[i - 1], 256), bufs[i]);
+    /* "Small Prefix Sum" */
+    scan_small(bufs[levels - 1], sizes[levels - 1]);
+    /* "Large Prefix Sum part 2", levels reversed */
+    for (int i = levels - 1; i >= 1; --i)
+        scan_large_down(bufs[i - 1], sizes[i - 1], bufs[i]);
+    scan_large_down(vals, len, bufs[0]);
+    for (int i = 0; i < levels; ++i) free(bufs[i]);
+}
+
+static uint32_t popc32(uint32_t x)
+{
+    x = x - ((x >> 1) & 0x55555555u);
+    x = (x & 0x33333333u) + ((x >> 2) & 0x33333333u);
+    return (((x + (x >> 4)) & 0x0F0F0F0Fu) * 0x01010101u) >> 24;
+}
+
+/* radix_sort_index.wgsl:185-253, modelled as in src/tests.rs:30-79: eight
+ * rounds; round k builds the 256-bit ballot of digit bit k, then row `wid` of
+ * the bitmap is AND-ed with the ballot if bit k of wid is set, else with its
+ * complement.  After eight rounds row d is the set of lanes whose digit is d.
+ * rank(t) = popcount(row[digit(t)] & lanes <= t) - 1. */
+void orc_ballot_rank_256(const uint32_t* digits_in, uint32_t nvalid,
+                         uint32_t* local_offset)
+{
+    static const uint32_t kTailDigit = 16000u; /* radix_sort_index.wgsl:267 */
+    uint32_t digits[256];
+    uint32_t bmp[256][8];
+    for (uint32_t t = 0; t < 256; ++t) {
+        digits[t] = t < nvalid ? digits_in[t] : kTailDigit;
+        for (int j = 0; j < 8; ++j) bmp[t][j] = 0xFFFFFFFFu;
+    }
+    for (uint32_t k = 0; k < 8; ++k) {
+        uint32_t ballot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t wid = 0; wid < 256; ++wid)
+            ballot[wid / 32] |= ((digits[wid] >> k) & 1u) << (wid % 32);
+        for (uint32_t wid = 0; wid < 256; ++wid)
+            for (int j = 0; j < 8; ++j)
+                bmp[wid][j] &= ((wid >> k) & 1u) ? ballot[j] : ~ballot[j];
+    }
+    for (uint32_t wid = 0; wid < 256; ++wid) {
+        /* the shader indexes the bitmap with the full digit; for tail lanes
+         * (digit 16000) that is outside the table -- they are never used. */
+        if (wid >= nvalid) { local_offset[wid] = 0; continue; }
+        uint32_t d = digits[wid];
+        uint32_t full = (wid + 1) / 32, rem = (wid + 1) % 32, count = 0;
+        for (uint32_t i = 0; i < full; ++i) count += popc32(bmp[d][i]);
+        if (rem) count += popc32(bmp[d][full] & ((1u << rem) - 1u));
+        local_offset[wid] = count - 1u;
+    }
+}
+
+/* radix_sort_index.wgsl:280-307.  final = rank + scanned[W*digit + block];
+ * the payload is read at the global index (the shader's `triangles[wid]` at
+ * :281 reads the local index, which is only right for block 0). */
+void orc_scatter(const uint32_t* keys_in, const uint32_t* vals_in,
+                 uint32_t* keys_out, uint32_t* vals_out, uint64_t n,
+                 int key_words, int payload_words, uint32_t shift,
+                 uint32_t bits, uint32_t tile, const uint32_t* scanned)
+{
+    uint64_t W = orc_div_ceil(n, tile);
+    uint64_t radix = 1ull << bits;
+    uint32_t* running = (uint32_t*)malloc((size_t)radix * sizeof(uint32_t));
+    for (uint64_t b = 0; b < W; ++b) {
+        memset(running, 0, (size_t)radix * sizeof(uint32_t));
+        uint64_t lo = b * tile, hi = lo + tile < n ? lo + tile : n;
+        for (uint64_t i = lo; i < hi; ++i) {
+            uint32_t d = orc_digit(keys_in + i * (uint64_t)key_words, key_words, shift, bits);
+            uint32_t rank = running[d]++;
+            uint64_t dst = (uint64_t)rank + scanned[W * d + b];
+            for (int w = 0; w < key_words; ++w)
+                keys_out[dst * key_words + w] = keys_in[i * key_words + w];
+            for (int w = 0; w < payload_words; ++w)
+                vals_out[dst * payload_words + w] = vals_in[i * payload_words + w];
+        }
+    }
+    free(running);
+}
+
+/* ------------------------------------------------------------------------- */
+/* whole sort                                                                 */
+/* ------------------------------------------------------------------------- */
+int orc_lsd_sort(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
+                 uint32_t* vals_b, uint64_t n, int key_words,
+                 int payload_words, uint32_t bits, uint32_t begin_bit,
+                 uint32_t end_bit, uint32_t tile, uint32_t* hist_tmp)
+{
+    uint32_t num_passes = (uint32_t)orc_div_ceil(end_bit - begin_bit, bits);
+    uint64_t W = orc_div_ceil(n, tile);
+    uint64_t hist_len = (1ull << bits) * W;
+    for (uint32_t p = 0; p < num_passes; ++p) {
+        /* ping-pong: src/main.rs:519-576 */
+        int even = (p % 2u) == 0u;
+        uint32_t* kin = even ? keys_a : keys_b;
+        uint32_t* vin = even ? vals_a : vals_b;
+        uint32_t* kout = even ? keys_b : keys_a;
+        uint32_t* vout = even ? vals_b : vals_a;
+        uint32_t shift = begin_bit + p * bits;
+        uint32_t pbits = shift + bits > end_bit ? end_bit - shift : bits;
+        /* a short last digit is sorted as a full-width digit whose upper bits
+         * are zero, so the histogram keeps `bits` columns */
+        orc_block_histogram(kin, n, key_words, shift, pbits, tile, hist_tmp);
+        if (pbits != bits) {
+            /* re-lay the narrower histogram out at full radix (zero bins) */
+            uint64_t nr = 1ull << pbits;
+            memset(hist_tmp + nr * W, 0, (size_t)(hist_len - nr * W) * sizeof(uint32_t));
+        }
+        orc_exclusive_scan(hist_tmp, hist_len);
+        orc_scatter(kin, vin, kout, vout, n, key_words, payload_words, shift,
+                    pbits, tile, hist_tmp);
+    }
+    return (num_passes % 2u) == 1u; /* src/main.rs:819-823 */
+}
+
+static uint64_t key_bits(const uint32_t* k, int key_words, uint32_t begin_bit, uint32_t end_bit)
+{
+    uint64_t v = k[0];
+    if (key_words == 2) v |= (uint64_t)k[1] << 32;
+    uint32_t width = end_bit - begin_bit;
+    v >>= begin_bit;
+    if (width < 64) v &= (1ull << width) - 1ull;
+    return v;
+}
+
+void orc_stable_sort_pairs(const uint32_t* keys_in, const uint32_t* vals_in,
+                           uint32_t* keys_out, uint32_t* vals_out, uint64_t n,
+                           int key_words, int payload_words,
+                           uint32_t begin_bit, uint32_t end_bit)
+{
+    /* bottom-up merge sort of an index permutation: stable by construction */
+    uint64_t* perm = (uint64_t*)malloc((size_t)(n ? n : 1) * sizeof(uint64_t));
+    uint64_t* tmp = (uint64_t*)malloc((size_t)(n ? n : 1) * sizeof(uint64_t));
+    uint64_t* kb = (uint64_t*)malloc((size_t)(n ? n : 1) * sizeof(uint64_t));
+    for (uint64_t i = 0; i < n; ++i) {
+        perm[i] = i;
+        kb[i] = key_bits(keys_in + i * (uint64_t)key_words, key_words, begin_bit, end_bit);
+    }
+    for (uint64_t width = 1; width < n; width *= 2) {
+        for (uint64_t lo = 0; lo < n; lo += 2 * width) {
+            uint64_t mid = lo + width < n ? lo + width : n;
+            uint64_t hi = lo + 2 * width < n ? lo + 2 * width : n;
+            uint64_t a = lo, b = mid, o = lo;
+            while (a < mid && b < hi) tmp[o++] = kb[perm[b]] < kb[perm[a]] ? perm[b++] : perm[a++];
+            while (a < mid) tmp[o++] = perm[a++];
+            while (b < hi) tmp[o++] = perm[b++];
+        }
+        uint64_t* s = perm; perm = tmp; tmp = s;
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t src = perm[i];
+        for (int w = 0; w < key_words; ++w) keys_out[i * key_words + w] = keys_in[src * key_words + w];
+        for (int w = 0; w < payload_words; ++w)
+            vals_out[i * payload_words + w] = vals_in[src * payload_words + w];
+    }
+    free(perm); free(tmp); free(kb);
+}
+
+/* src/main.rs:831-856 */
+uint64_t orc_count_unsorted(const uint32_t* keys, uint64_t n, int key_words,
+                            uint32_t num_passes_of_8)
+{
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i + 1 < n; ++i) {
+        uint64_t a = key_bits(keys + i * (uint64_t)key_words, key_words, 0, 64);
+        uint64_t b = key_bits(keys + (i + 1) * (uint64_t)key_words, key_words, 0, 64);
+        if (key_words == 1) { a &= 0xFFFFFFFFull; b &= 0xFFFFFFFFull; }
+        if (orc_select_bits(a, num_passes_of_8) > orc_select_bits(b, num_passes_of_8)) bad++;
+    }
+    return bad;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Morton encoders                                                            */
+/* ------------------------------------------------------------------------- */
+/* f32 -> u32 as the HIP side does it: toward zero, NaN and negatives to 0,
+ * values >= 2^32 to 0xFFFFFFFF. */
+static uint32_t f2u_sat(float f)
+{
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+
+static float rd_f32(const unsigned char* p) { float f; memcpy(&f, p, 4); return f; }
+static uint32_t rd_u32(const unsigned char* p) { uint32_t u; memcpy(&u, p, 4); return u; }
+
+/* morton_code.wgsl:42-46 */
+static int translate_coords_lut(int i, int byte, int first_or_last)
+{
+    return i * 512 + (byte & 0xFF) * 2 + first_or_last;
+}
+
+/* morton_code.wgsl:103-127 (one item of the unrolled entry point) */
+void orc_morton_encode_lut(const void* blob_v, const void* vertices_v,
+                           const void* triangles_v, uint64_t n, uint32_t* codes)
+{
+    const unsigned char* blob = (const unsigned char*)blob_v;
+    const unsigned char* verts = (const unsigned char*)vertices_v;
+    const unsigned char* tris = (const unsigned char*)triangles_v;
+    const uint32_t* lut = (const uint32_t*)blob;                 /* @0      */
+    const uint32_t* size_lut = (const uint32_t*)(blob + 18432);  /* @18432  */
+    float offset[3], multiplier[3];
+    for (int c = 0; c < 3; ++c) {
+        offset[c] = rd_f32(blob + 51216 + 4 * c);
+        multiplier[c] = rd_f32(blob + 51232 + 4 * c);
+    }
+    float size_multiplier = rd_f32(blob + 51228);
+    for (uint64_t t = 0; t < n; ++t) {
+        float mn[3], mx[3];
+        for (int c = 0; c < 3; ++c) {
+            float v[3];
+            for (int k = 0; k < 3; ++k) {
+                uint32_t vi = rd_u32(tris + t * 16 + 4 * k);
+                v[k] = rd_f32(verts + (uint64_t)vi * 48 + 4 * c);
+            }
+            mn[c] = fminf(fminf(v[0], v[1]), v[2]);
+            mx[c] = fmaxf(fmaxf(v[0], v[1]), v[2]);
+        }
+        uint32_t p[3];
+        float d[3];
+        for (int c = 0; c < 3; ++c) {
+            float centre = (mn[c] + mx[c]) * 0.5f;
+            p[c] = f2u_sat((centre - offset[c]) * multiplier[c] - 0.001f);
+            d[c] = mx[c] - mn[c];
+        }
+        float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        uint32_t j = f2u_sat(len * size_multiplier);
+        /* the size table has 4096 entries; an index past it is out of bounds
+         * in the shader (result implementation-defined) -- clamp */
+        if (j > 4095u) j = 4095u;
+        uint32_t lo = 0, hi = 0;
+        for (int i = 0; i < 3; ++i) {
+            /* the shift is i*3 as written at morton_code.wgsl:113-115 */
+            for (int c = 0; c < 3; ++c) {
+                int byte = (int)(p[c] >> (3u * (uint32_t)i));
+                lo |= lut[translate_coords_lut(c + 3 * i, byte, 0)];
+                hi |= lut[translate_coords_lut(c + 3 * i, byte, 1)];
+            }
+        }
+        lo |= size_lut[j * 2u];
+        hi |= size_lut[j * 2u + 1u];
+        codes[t * 2] = lo;
+        codes[t * 2 + 1] = hi;
+    }
+}
+
+static uint32_t spread10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+void orc_morton_encode30(const float* xyz, uint64_t n, const float* mn,
+                         const float* mx, uint32_t* keys, uint32_t* idx)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t u[3];
+        for (int c = 0; c < 3; ++c) {
+            float q = (xyz[3 * i + c] - mn[c]) / (mx[c] - mn[c]);
+            float t = fminf(fmaxf(q * 1024.0f, 0.0f), 1023.0f);
+            u[c] = f2u_sat(t);
+        }
+        keys[i] = (spread10(u[0]) << 2) | (spread10(u[1]) << 1) | spread10(u[2]);
+        idx[i] = (uint32_t)i;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* generator: splitmix64-style counter hash                                   */
+/* ------------------------------------------------------------------------- */
+static uint64_t mix64(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+uint32_t orc_rand_u32(uint64_t seed, uint64_t stream, uint64_t index)
+{
+    uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ull * (stream + 1ull));
+    return (uint32_t)(mix64(k + 0x9E3779B97F4A7C15ull * (index + 1ull)) >> 32);
+}
+
+void orc_gen_points(uint64_t seed, uint64_t n, float* xyz)
+{
+    for (uint64_t i = 0; i < n; ++i)
+        for (uint64_t c = 0; c < 3; ++c)
+            xyz[3 * i + c] = (float)(orc_rand_u32(seed, c, i) >> 8) * (1.0f / 16777216.0f);
+}
+
+void orc_gen_u32(uint64_t seed, uint64_t stream, uint64_t n, uint32_t* out)
+{
+    for (uint64_t i = 0; i < n; ++i) out[i] = orc_rand_u32(seed, stream, i);
+}
+
+void orc_minmax3(const float* xyz, uint64_t n, float* mn, float* mx)
+{
+    for (int c = 0; c < 3; ++c) { mn[c] = INFINITY; mx[c] = -INFINITY; }
+    for (uint64_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            mn[c] = fminf(mn[c], xyz[3 * i + c]);
+            mx[c] = fmaxf(mx[c], xyz[3 * i + c]);
+        }
+}
+
+/* ------------------------------------------------------------------------- */
+/* restated unit tests of src/tests.rs                                        */
+/* ------------------------------------------------------------------------- */
+/* src/tests.rs:30-102.  The reference draws digits from ChaCha8Rng(seed); the
+ * property asserted (placement by exclusive-scan + ballot rank is sorted) does
+ * not depend on the generator, so this repo's counter hash supplies them. */
+int orc_selftest_workgroup_local_index(uint32_t num_seeds)
+{
+    for (uint32_t seed = 0; seed < num_seeds; ++seed) {
+        uint32_t digits[256], local_offset[256], hist[256], psum[256], out[256];
+        for (uint32_t i = 0; i < 256; ++i) digits[i] = orc_rand_u32(seed, 99, i) & 255u;
+        orc_ballot_rank_256(digits, 256, local_offset);
+        memset(hist, 0, sizeof hist);
+        for (uint32_t i = 0; i < 256; ++i) hist[digits[i]]++;
+        uint32_t s = 0;
+        for (uint32_t d = 0; d < 256; ++d) { psum[d] = s; s += hist[d]; }
+        /* additionally compare with the direct count the reference computes
+         * but never asserts (src/tests.rs:80-85) */
+        uint32_t seen[256];
+        memset(seen, 0, sizeof seen);
+        for (uint32_t i = 0; i < 256; ++i) {
+            if (local_offset[i] != seen[digits[i]]++) return 2;
+            out[psum[digits[i]] + local_offset[i]] = digits[i];
+        }
+        for (uint32_t i = 0; i + 1 < 256; ++i)
+            if (out[i] > out[i + 1]) return 1;
+    }
+    return 0;
+}
+
+/* src/tests.rs:104-113 */
+int orc_selftest_workgroup_calculation(void)
+{
+    if (orc_num_workgroups(0, 256) != 0) return 1;
+    for (uint64_t i = 1; i < 256; ++i) if (orc_num_workgroups(i, 256) != 1) return 2;
+    for (uint64_t i = 257; i < 512; ++i) if (orc_num_workgroups(i, 256) != 2) return 3;
+    return 0;
+}
+
+/* src/tests.rs:115-130 */
+int orc_selftest_digit6(void)
+{
+    for (uint32_t i = 0; i < 11; ++i) {
+        uint64_t y = 63ull << (i * 6u);
+        uint32_t hi = (uint32_t)(y >> 32), lo = (uint32_t)(y & 0xFFFFFFFFull);
+        uint32_t sel = orc_select_digit6(i, lo, hi);
+        if (i < 10 ? sel != 63u : sel != 15u) return 1 + (int)i;
+    }
+    return 0;
+}
+
+/* src/tests.rs:132-143 */
+int orc_selftest_digit8(void)
+{
+    for (uint32_t i = 0; i < 8; ++i) {
+        uint64_t y = 255ull << (i * 8u);
+        uint32_t hi = (uint32_t)(y >> 32), lo = (uint32_t)(y & 0xFFFFFFFFull);
+        if (orc_select_digit8(i, lo, hi) != 255u) return 1 + (int)i;
+        if (orc_digit((uint32_t[]){lo, hi}, 2, i * 8u, 8) != 255u) return 100 + (int)i;
+    }
+    return 0;
+}

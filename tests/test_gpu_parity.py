@@ -1,0 +1,300 @@
+"""GPU parity tests: every call goes through the C ABI of libmrs.so and is compared
+bit-for-bit with the CPU oracle on the same seeded input."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import gpu_sort, to_dev, to_u32
+from inputs import DISTRIBUTIONS, make_keys, make_vals
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def mrs():
+    import wgpu_morton_code_radix_sort_test_amd as m
+
+    return m
+
+
+# ---- generators and encoders ---------------------------------------------------------
+def test_generators_match_oracle(ctx, oracle):
+    for n in (1, 1000, 65537):
+        xyz = ctx.generate_points(7, n).cpu().numpy()
+        assert np.array_equal(xyz.view(np.uint32), oracle.gen_points(7, n).view(np.uint32))
+        u = to_u32(ctx.generate_u32(9, 3, n))
+        assert np.array_equal(u, oracle.gen_u32(9, 3, n))
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1023, 65536, 100003])
+def test_morton_encode30_matches_oracle(ctx, oracle, n):
+    xyz = oracle.gen_points(7, n)
+    mn, mx = oracle.minmax3(xyz)
+    keys, idx = ctx.morton_encode30(to_dev(xyz, ctx.device), mn, mx)
+    rk, ri = oracle.morton_encode30(xyz, mn, mx)
+    assert np.array_equal(to_u32(keys), rk)
+    assert np.array_equal(to_u32(idx), ri)
+    # bounds tighter than the data: exercises the clamp on both sides
+    mn2 = np.array([0.2, 0.1, 0.3], dtype=np.float32)
+    mx2 = np.array([0.7, 0.9, 0.8], dtype=np.float32)
+    keys, _ = ctx.morton_encode30(to_dev(xyz, ctx.device), mn2, mx2)
+    assert np.array_equal(to_u32(keys), oracle.morton_encode30(xyz, mn2, mx2)[0])
+
+
+@pytest.mark.parametrize("nv,nt", [(3, 1), (1000, 3000), (5000, 70001)])
+def test_morton_encode_lut_matches_oracle(ctx, oracle, mrs, nv, nt):
+    positions, indices, gen = mrs.scene.create_scene(nv, nt, 7)
+    verts = mrs.scene.pack_vertices(positions)
+    tris = mrs.scene.pack_triangles(indices)
+    for blob in (mrs.scene.create_morton_uniforms(gen),
+                 mrs.scene.random_uniforms_blob(5, gen.offset, gen.multiplier, gen.size_multiplier),
+                 # offset inside the scene and a huge multiplier: negative and overflowing quantised values
+                 mrs.scene.random_uniforms_blob(6, [0.5, 0.5, 0.5], [3e9, 1e10, 512.0], 1e6)):
+        codes = ctx.morton_encode_lut(to_dev(blob, ctx.device), to_dev(verts, ctx.device), to_dev(tris, ctx.device))
+        assert np.array_equal(to_u32(codes), oracle.morton_encode_lut(blob, verts, tris))
+
+
+# ---- single stages of the three-kernel pass ------------------------------------------
+@pytest.mark.parametrize("tile", [256, 1024, 8192])
+@pytest.mark.parametrize("bits", [4, 8])
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 3000, 70000])
+def test_stages_match_oracle(ctx, oracle, mrs, tile, bits, n):
+    keys = make_keys(oracle, n, 1, "random")
+    vals = make_vals(oracle, n, 1)
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=bits, algo=mrs.ALGO_THREE_KERNEL,
+                        tile_items=tile)
+    assert plan.info.tile_items == tile
+    dk, dv = to_dev(keys, ctx.device), to_dev(vals, ctx.device)
+    for p in (0, plan.info.num_passes - 1):
+        shift = p * bits
+        hist = plan.histogram(dk, p)
+        ref_hist = oracle.block_histogram(keys, n, 1, shift, bits, tile)
+        assert np.array_equal(to_u32(hist), ref_hist)
+        plan.scan(hist)
+        ref_scan = oracle.exclusive_scan(ref_hist)
+        assert np.array_equal(to_u32(hist), ref_scan)
+        ko, vo = torch.empty_like(dk), torch.empty_like(dv)
+        plan.scatter(dk, dv, ko, vo, hist, p)
+        rk, rv = oracle.scatter(keys, vals, n, 1, 1, shift, bits, tile, ref_scan)
+        assert np.array_equal(to_u32(ko), rk)
+        assert np.array_equal(to_u32(vo), rv)
+    plan.close()
+
+
+def test_reference_histogram_layout(ctx, oracle, mrs):
+    """tile_items = 256 reproduces the reference's [256][ceil(n/256)] histogram and its
+    hierarchical prefix sum for the shipped 3000-element case (src/main.rs:377-381)."""
+    n = 3000
+    keys = make_keys(oracle, n, 2, "random")
+    plan = mrs.SortPlan(ctx, n, key_words=2, payload_bytes=16, digit_bits=8, algo=mrs.ALGO_THREE_KERNEL,
+                        tile_items=256)
+    assert plan.info.max_tiles == 12 and plan.info.histogram_len == 3072 and plan.info.num_passes == 8
+    dk = to_dev(keys, ctx.device)
+    for p in range(8):
+        hist = plan.histogram(dk, p)
+        ref = oracle.block_histogram(keys, n, 2, 8 * p, 8, 256)
+        assert np.array_equal(to_u32(hist), ref)
+        plan.scan(hist)
+        assert np.array_equal(to_u32(hist), oracle.hierarchical_scan(ref))
+
+
+def test_large_scan(ctx, oracle, mrs):
+    # 2^20 keys at 256 per tile: a 2^20-entry histogram (three scan kernels)
+    n = 1 << 20
+    keys = make_keys(oracle, n, 1, "random")
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=0, digit_bits=8, algo=mrs.ALGO_THREE_KERNEL,
+                        tile_items=256)
+    hist = plan.histogram(to_dev(keys, ctx.device), 1)
+    ref = oracle.block_histogram(keys, n, 1, 8, 8, 256)
+    assert np.array_equal(to_u32(hist), ref)
+    plan.scan(hist)
+    assert np.array_equal(to_u32(hist), oracle.exclusive_scan(ref))
+
+
+# ---- the whole sort ---------------------------------------------------------------------
+SHAPES = [(1, 0), (1, 1), (2, 0), (2, 1), (2, 4)]
+SIZES = [0, 1, 255, 256, 257, 3000, 8191, 8192, 8193, 65536, 200001]
+
+
+@pytest.mark.parametrize("algo_name", ["three_kernel", "onesweep"])
+@pytest.mark.parametrize("key_words,payload_words", SHAPES)
+@pytest.mark.parametrize("bits", [4, 8])
+def test_sort_matches_oracle(ctx, oracle, mrs, algo_name, key_words, payload_words, bits):
+    algo = mrs.ALGO_ONESWEEP if algo_name == "onesweep" else mrs.ALGO_THREE_KERNEL
+    end = 32 * key_words
+    for n in SIZES:
+        keys = make_keys(oracle, n, key_words, "random", seed=n + 1)
+        vals = make_vals(oracle, n, payload_words)
+        ko, vo, in_b = gpu_sort(ctx, mrs, keys, vals, n, key_words, payload_words, bits, 0, end, algo)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, key_words, payload_words, 0, end)
+        assert in_b == ((end // bits) % 2 == 1)
+        assert np.array_equal(ko, rk), (n, "keys")
+        if payload_words:
+            assert np.array_equal(vo, rv), (n, "payload")
+
+
+@pytest.mark.parametrize("algo_name", ["three_kernel", "onesweep"])
+@pytest.mark.parametrize("dist", DISTRIBUTIONS)
+def test_sort_distributions(ctx, oracle, mrs, algo_name, dist):
+    algo = mrs.ALGO_ONESWEEP if algo_name == "onesweep" else mrs.ALGO_THREE_KERNEL
+    for key_words, payload_words, n in ((1, 1, 100000), (2, 4, 20000)):
+        keys = make_keys(oracle, n, key_words, dist)
+        vals = make_vals(oracle, n, payload_words)
+        end = 32 * key_words
+        ko, vo, _ = gpu_sort(ctx, mrs, keys, vals, n, key_words, payload_words, 8, 0, end, algo)
+        # oracle with the reference's pass structure, then the independent stable sort
+        rk, rv, _ = oracle.lsd_sort(keys, vals, n, key_words, payload_words, 8, 0, end, 256)
+        assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+        sk, sv = oracle.stable_sort_pairs(keys, vals, n, key_words, payload_words, 0, end)
+        assert np.array_equal(ko, sk) and np.array_equal(vo, sv)
+
+
+@pytest.mark.parametrize("tile", [256, 1024, 4096, 8192])
+@pytest.mark.parametrize("algo_name", ["three_kernel", "onesweep"])
+def test_sort_tile_shapes(ctx, oracle, mrs, tile, algo_name):
+    algo = mrs.ALGO_ONESWEEP if algo_name == "onesweep" else mrs.ALGO_THREE_KERNEL
+    n = 50001
+    keys = make_keys(oracle, n, 1, "morton30")
+    vals = make_vals(oracle, n, 1)
+    ko, vo, _ = gpu_sort(ctx, mrs, keys, vals, n, 1, 1, 8, 0, 32, algo, tile_items=tile)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+@pytest.mark.parametrize("begin,end,bits", [(0, 30, 8), (4, 20, 8), (0, 30, 4), (3, 11, 8), (0, 8, 8)])
+def test_sort_bit_ranges(ctx, oracle, mrs, begin, end, bits):
+    n = 30000
+    keys = make_keys(oracle, n, 1, "random")
+    vals = make_vals(oracle, n, 1)
+    for algo in (mrs.ALGO_THREE_KERNEL, mrs.ALGO_ONESWEEP):
+        ko, vo, in_b = gpu_sort(ctx, mrs, keys, vals, n, 1, 1, bits, begin, end, algo)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, begin, end)
+        assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+        assert in_b == ((-(-(end - begin) // bits)) % 2 == 1)
+
+
+def test_plan_capacity_larger_than_n(ctx, oracle, mrs):
+    """A plan sized for more elements sorts fewer, repeatedly (state is reset per call)."""
+    cap = 100000
+    plan = mrs.SortPlan(ctx, cap, key_words=1, payload_bytes=4, digit_bits=8, algo=mrs.ALGO_ONESWEEP)
+    for n in (cap, 12345, 1, 77777):
+        keys = make_keys(oracle, n, 1, "random", seed=n)
+        vals = make_vals(oracle, n, 1)
+        ka, va = to_dev(keys, ctx.device), to_dev(vals, ctx.device)
+        kb, vb = torch.empty_like(ka), torch.empty_like(va)
+        in_b = plan.sort_pairs(ka, va, kb, vb, n=n)
+        plan.check()
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+        assert np.array_equal(to_u32(kb if in_b else ka), rk)
+        assert np.array_equal(to_u32(vb if in_b else va), rv)
+
+
+def test_config1_2pow20_4bit_three_kernel(ctx, oracle, mrs):
+    """BASELINE config 1: 2^20 u32 Morton keys, 4-bit-digit LSD radix (8 passes)."""
+    n = 1 << 20
+    keys = make_keys(oracle, n, 1, "morton30")
+    vals = make_vals(oracle, n, 1)
+    ko, vo, in_b = gpu_sort(ctx, mrs, keys, vals, n, 1, 1, 4, 0, 32, mrs.ALGO_THREE_KERNEL)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+    assert not in_b
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+# ---- golden vectors --------------------------------------------------------------------------
+def test_golden_vectors_on_gpu(ctx, mrs):
+    files = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+    assert files
+    for f in files:
+        g = np.load(f)
+        kind = str(g["kind"])
+        if kind == "sort":
+            kw, pw, n = int(g["key_words"]), int(g["payload_words"]), int(g["n"])
+            vals = g["vals_in"] if pw else None
+            for algo in (mrs.ALGO_THREE_KERNEL, mrs.ALGO_ONESWEEP):
+                for tile in (int(g["tile"]), 0):
+                    ko, vo, in_b = gpu_sort(ctx, mrs, g["keys_in"], vals, n, kw, pw, int(g["bits"]),
+                                            int(g["begin_bit"]), int(g["end_bit"]), algo, tile_items=tile)
+                    assert np.array_equal(ko, g["keys_out"]), f
+                    if pw:
+                        assert np.array_equal(vo, g["vals_out"]), f
+                    assert in_b == bool(g["result_in_b"]), f
+        elif kind == "encode30":
+            k, i = ctx.morton_encode30(to_dev(g["xyz"], ctx.device), g["mn"], g["mx"])
+            assert np.array_equal(to_u32(k), g["keys"]) and np.array_equal(to_u32(i), g["idx"]), f
+        elif kind == "encode_lut":
+            codes = ctx.morton_encode_lut(to_dev(g["blob"], ctx.device), to_dev(g["vertices"], ctx.device),
+                                          to_dev(g["triangles"], ctx.device))
+            assert np.array_equal(to_u32(codes), g["codes"]), f
+
+
+# ---- the reference's entry points ---------------------------------------------------------------
+@pytest.mark.parametrize("algo_name", ["three_kernel", "onesweep"])
+def test_run_headless(ctx, oracle, mrs, algo_name):
+    """run_headless on the shipped scene size: the reference's adjacent-pair check
+    (src/main.rs:831-864) plus full key AND payload parity with the oracle."""
+    algo = mrs.ALGO_ONESWEEP if algo_name == "onesweep" else mrs.ALGO_THREE_KERNEL
+    res = mrs.run_headless(0, algo=algo, tile_items=256 if algo_name == "three_kernel" else 0)
+    assert res["sorted"] and not res["all_zero"] and res["times_unsorted"] == 0
+    host = res["buffers"].host
+    verts = mrs.scene.pack_vertices(host["positions"])
+    tris = mrs.scene.pack_triangles(host["indices"])
+    codes = oracle.morton_encode_lut(host["uniforms"], verts, tris)
+    n = host["indices"].shape[0]
+    rk, rv, in_b = oracle.lsd_sort(codes, tris.view(np.uint32), n, 2, 4, 8, 0, 64, 256)
+    assert in_b == res["buffers"].result_in_2 == False  # noqa: E712  (8 passes: result in the first buffers)
+    assert np.array_equal(res["keys"].view(np.uint32), rk)
+    assert np.array_equal(res["triangles"], rv.reshape(-1, 4)[:, :3])
+
+
+# ---- multi-GPU building blocks ----------------------------------------------------------------------
+def test_bucket_histogram(ctx, oracle):
+    n = 300001
+    keys = make_keys(oracle, n, 1, "morton30")
+    for shift, bits in ((18, 12), (22, 8), (0, 4)):
+        counts = ctx.bucket_histogram(to_dev(keys, ctx.device), n, 1, shift, bits).cpu().numpy()
+        ref = np.bincount((keys >> np.uint32(shift)) & np.uint32((1 << bits) - 1), minlength=1 << bits)
+        assert np.array_equal(counts, ref)
+
+
+@pytest.mark.parametrize("bits_plan", [4, 8])
+def test_partition(ctx, oracle, mrs, bits_plan):
+    n = 250007
+    keys = make_keys(oracle, n, 1, "morton30")
+    vals = make_vals(oracle, n, 1)
+    shift, bits, parts = 18, 12, 8
+    bucket = (keys >> np.uint32(shift)) & np.uint32((1 << bits) - 1)
+    bmap = (np.arange(1 << bits) * parts // (1 << bits)).astype(np.uint8)
+    bmap[5] = 7  # a non-monotone entry: the map is a table, not a shift
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=bits_plan, algo=mrs.ALGO_ONESWEEP)
+    ka, va = to_dev(keys, ctx.device), to_dev(vals, ctx.device)
+    kb, vb = torch.empty_like(ka), torch.empty_like(va)
+    counts = plan.partition(ka, va, kb, vb, shift, bits, torch.from_numpy(bmap).to(ctx.device), parts)
+    plan.check()
+    dest = bmap[bucket]
+    order = np.argsort(dest, kind="stable")
+    assert np.array_equal(to_u32(kb), keys[order])
+    assert np.array_equal(to_u32(vb), vals[order])
+    assert np.array_equal(to_u32(counts)[:parts], np.bincount(dest, minlength=parts))
+
+
+# ---- error behaviour ------------------------------------------------------------------------------------
+def test_errors_are_reported(ctx, mrs):
+    with pytest.raises(mrs.MrsError):
+        mrs.SortPlan(ctx, 1000, key_words=3)
+    with pytest.raises(mrs.MrsError):
+        mrs.SortPlan(ctx, 1000, digit_bits=5)
+    with pytest.raises(mrs.MrsError):
+        mrs.SortPlan(ctx, 0)
+    with pytest.raises(mrs.MrsError):
+        mrs.SortPlan(ctx, 1000, key_words=1, payload_bytes=16, tile_items=8192)
+    plan = mrs.SortPlan(ctx, 1000)
+    k = torch.zeros(2000, dtype=torch.int32, device=ctx.device)
+    with pytest.raises(mrs.MrsError):
+        plan.sort_pairs(k, k, k, k, n=1000)  # A and B must differ
+    with pytest.raises(mrs.MrsError):
+        plan.sort_pairs(k, k, k.clone(), k.clone(), n=2000)  # beyond capacity

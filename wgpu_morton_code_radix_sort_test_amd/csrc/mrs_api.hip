@@ -1,0 +1,518 @@
+// C ABI of libmrs.so: contexts, plans and the launch schedule of the sort.
+//
+// mrs_sort_pairs is the host side of the reference's pass loop
+// (src/main.rs:594-665): for every digit it enqueues the histogram, prefix-sum
+// and scatter stages on one stream with ping-pong buffers
+// (src/main.rs:515-576), with no host synchronisation in between.
+#include <cstring>
+#include <string>
+
+#include "mrs_internal.h"
+#include "mrs_radix_impl.hpp"
+
+namespace mrs {
+
+static thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+void clear_error() { g_last_error.clear(); }
+
+// per-key-type entry points (mrs_radix_u32.hip / mrs_radix_u64.hip)
+int launch_pass_u32(int mode, int bits, int threads, int kpt, int payload_bytes, const PassArgs& a, hipStream_t s);
+int launch_pass_u64(int mode, int bits, int threads, int kpt, int payload_bytes, const PassArgs& a, hipStream_t s);
+int launch_block_histogram_u32(int bits, uint32_t n, const void* keys, uint32_t tile_items, uint32_t num_tiles,
+                               uint32_t shift, uint32_t mask, uint32_t* hist, hipStream_t s);
+int launch_block_histogram_u64(int bits, uint32_t n, const void* keys, uint32_t tile_items, uint32_t num_tiles,
+                               uint32_t shift, uint32_t mask, uint32_t* hist, hipStream_t s);
+int launch_global_histogram_u32(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
+int launch_global_histogram_u64(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
+
+bool config_supported(int key_words, int payload_bytes, int digit_bits, int tile_items, int algo, KernelConfig* cfg)
+{
+    (void)algo;
+    if (key_words != 1 && key_words != 2) return false;
+    if (payload_bytes != 0 && payload_bytes != 4 && payload_bytes != 16) return false;
+    if (digit_bits != 4 && digit_bits != 8) return false;
+    KernelConfig c;
+    switch (tile_items) {
+        case 0:
+            if (payload_bytes == 16) c = {256, 4};
+            else if (key_words == 2) c = {512, 8};
+            else c = {512, 16};
+            break;
+        case 256: c = {256, 1}; break;
+        case 1024: c = {256, 4}; break;
+        case 4096: c = {512, 8}; break;
+        case 8192: c = {512, 16}; break;
+        default: return false;
+    }
+    const bool large = c.threads == 512;
+    if (large && payload_bytes == 16) return false;
+    if (c.threads == 512 && c.kpt == 16 && key_words == 2) return false;
+    if (cfg) *cfg = c;
+    return true;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+constexpr size_t kControlBytes = (sizeof(OnesweepControl) + 255) / 256 * 256;
+
+static int check_device(const mrs_context* ctx, const char* who)
+{
+    int cur = -1;
+    MRS_HIP_TRY(hipGetDevice(&cur));
+    if (cur != ctx->device)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "%s: context is for device %d but the current device is %d", who,
+                    ctx->device, cur);
+    return MRS_OK;
+}
+
+static uint32_t pass_shift(const mrs_plan* p, uint32_t pass) { return p->desc.begin_bit + pass * p->radix_bits; }
+static uint32_t pass_mask(const mrs_plan* p, uint32_t pass)
+{
+    const uint32_t shift = pass_shift(p, pass);
+    const uint32_t width = p->desc.end_bit - shift < p->radix_bits ? p->desc.end_bit - shift : p->radix_bits;
+    return (1u << width) - 1u;
+}
+
+static int launch_pass(const mrs_plan* p, int mode, const PassArgs& a, hipStream_t s)
+{
+    if (p->desc.key_words == 1)
+        return launch_pass_u32(mode, p->radix_bits, p->threads, p->kpt, p->desc.payload_bytes, a, s);
+    return launch_pass_u64(mode, p->radix_bits, p->threads, p->kpt, p->desc.payload_bytes, a, s);
+}
+
+static int launch_block_hist(const mrs_plan* p, uint32_t n, const void* keys, uint32_t num_tiles, uint32_t pass,
+                             uint32_t* hist, hipStream_t s)
+{
+    if (p->desc.key_words == 1)
+        return launch_block_histogram_u32(p->radix_bits, n, keys, p->tile_items, num_tiles, pass_shift(p, pass),
+                                          pass_mask(p, pass), hist, s);
+    return launch_block_histogram_u64(p->radix_bits, n, keys, p->tile_items, num_tiles, pass_shift(p, pass),
+                                      pass_mask(p, pass), hist, s);
+}
+
+static int launch_global_hist(const mrs_plan* p, const GlobalHistArgs& a, hipStream_t s)
+{
+    const uint64_t vec = p->desc.key_words == 1 ? 4 : 2;
+    uint64_t blocks = (a.n / vec + 255) / 256;
+    const uint64_t cap = static_cast<uint64_t>(p->ctx->num_cus) * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    if (p->desc.key_words == 1) return launch_global_histogram_u32(p->radix_bits, static_cast<int>(blocks), a, s);
+    return launch_global_histogram_u64(p->radix_bits, static_cast<int>(blocks), a, s);
+}
+
+static int launch_ghist_scan(const mrs_plan* p, uint32_t num_passes, hipStream_t s)
+{
+    const unsigned threads = p->radix < 64 ? 64 : p->radix;
+    if (p->radix_bits == 4)
+        hipLaunchKernelGGL(global_histogram_scan_kernel<4>, dim3(num_passes), dim3(threads), 0, s, p->control->ghist);
+    else
+        hipLaunchKernelGGL(global_histogram_scan_kernel<8>, dim3(num_passes), dim3(threads), 0, s, p->control->ghist);
+    MRS_CHECK_LAUNCH("global_histogram_scan_kernel");
+    return MRS_OK;
+}
+
+static int validate_call(const mrs_plan* plan, uint64_t n, const char* who)
+{
+    if (!plan) return fail(MRS_ERR_INVALID_ARGUMENT, "%s: null plan", who);
+    if (n > plan->desc.n) return fail(MRS_ERR_INVALID_ARGUMENT, "%s: n = %llu exceeds the plan capacity %llu", who,
+                                      (unsigned long long)n, (unsigned long long)plan->desc.n);
+    return check_device(plan->ctx, who);
+}
+
+static bool misaligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; }
+
+// ---- bucket histogram (multi-GPU split) ---------------------------------------------
+template <typename KeyT>
+__global__ __launch_bounds__(256) void bucket_histogram_kernel(const KeyT* __restrict__ keys, unsigned long long n,
+                                                                uint32_t shift, uint32_t bins,
+                                                                unsigned long long* __restrict__ counts)
+{
+    extern __shared__ uint32_t s_bins[];
+    for (uint32_t j = threadIdx.x; j < bins; j += 256) s_bins[j] = 0;
+    __syncthreads();
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256;
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride)
+        atomicAdd(&s_bins[static_cast<uint32_t>(keys[i] >> shift) & (bins - 1)], 1u);
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < bins; j += 256) {
+        const uint32_t c = s_bins[j];
+        if (c) atomicAdd(&counts[j], static_cast<unsigned long long>(c));
+    }
+}
+
+}  // namespace mrs
+
+using namespace mrs;
+
+extern "C" const char* mrs_last_error_string(void) { return g_last_error.c_str(); }
+
+extern "C" int mrs_version(void) { return (MRS_VERSION_MAJOR << 16) | MRS_VERSION_MINOR; }
+
+extern "C" int mrs_context_create(int device_id, mrs_context** out)
+{
+    clear_error();
+    if (!out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_create: null output pointer");
+    *out = nullptr;
+    int count = 0;
+    MRS_HIP_TRY(hipGetDeviceCount(&count));
+    if (device_id < 0 || device_id >= count)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_create: device %d out of range (%d devices)", device_id, count);
+    hipDeviceProp_t prop;
+    MRS_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MRS_ERR_UNSUPPORTED, "mrs_context_create: device %d is %s; this library is built for gfx950 only",
+                    device_id, prop.gcnArchName);
+    mrs_context* c = new mrs_context;
+    c->device = device_id;
+    c->num_cus = prop.multiProcessorCount;
+    *out = c;
+    return MRS_OK;
+}
+
+extern "C" int mrs_context_destroy(mrs_context* ctx)
+{
+    clear_error();
+    delete ctx;
+    return MRS_OK;
+}
+
+extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_plan** out)
+{
+    clear_error();
+    if (!ctx || !d || !out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_create: null argument");
+    *out = nullptr;
+    if (int rc = check_device(ctx, "mrs_plan_create")) return rc;
+    if (d->n == 0 || d->n >= 0xFFFFFFFFull)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_create: n must satisfy 0 < n < 2^32 - 1");
+    if (d->algo != MRS_ALGO_THREE_KERNEL && d->algo != MRS_ALGO_ONESWEEP)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_create: unknown algo %d", d->algo);
+    KernelConfig cfg;
+    if (!config_supported(d->key_words, d->payload_bytes, d->digit_bits, d->tile_items, d->algo, &cfg))
+        return fail(MRS_ERR_UNSUPPORTED,
+                    "mrs_plan_create: unsupported shape (key_words %d, payload_bytes %d, digit_bits %d, tile_items %d)",
+                    d->key_words, d->payload_bytes, d->digit_bits, d->tile_items);
+    const int key_bits = 32 * d->key_words;
+    if (d->begin_bit < 0 || d->end_bit > key_bits || d->begin_bit >= d->end_bit)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_create: bit range [%d, %d) invalid for a %d-bit key",
+                    d->begin_bit, d->end_bit, key_bits);
+
+    mrs_plan* p = new mrs_plan();
+    p->ctx = ctx;
+    p->desc = *d;
+    p->radix_bits = d->digit_bits;
+    p->radix = 1u << d->digit_bits;
+    p->num_passes = (d->end_bit - d->begin_bit + d->digit_bits - 1) / d->digit_bits;
+    p->threads = cfg.threads;
+    p->kpt = cfg.kpt;
+    p->tile_items = cfg.threads * cfg.kpt;
+    p->desc.tile_items = p->tile_items;
+    p->max_tiles = (d->n + p->tile_items - 1) / p->tile_items;
+    p->histogram_len = static_cast<uint64_t>(p->radix) * p->max_tiles;
+    if (p->num_passes > static_cast<uint32_t>(kMaxPasses)) {
+        delete p;
+        return fail(MRS_ERR_UNSUPPORTED, "mrs_plan_create: too many passes");
+    }
+
+    size_t bytes = 0;
+    if (d->algo == MRS_ALGO_THREE_KERNEL) {
+        const size_t hist_bytes = align_up(p->histogram_len * sizeof(uint32_t), 256);
+        p->scan_partials_len = scan_partials_len(p->histogram_len);
+        const size_t part_bytes = align_up(p->scan_partials_len * sizeof(uint32_t), 256);
+        bytes = hist_bytes + part_bytes;
+        hipError_t e = hipMalloc(&p->temp, bytes);
+        if (e != hipSuccess) {
+            delete p;
+            return fail(MRS_ERR_OUT_OF_MEMORY, "mrs_plan_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        }
+        p->hist = static_cast<uint32_t*>(p->temp);
+        p->scan_partials = reinterpret_cast<uint32_t*>(static_cast<char*>(p->temp) + hist_bytes);
+    } else {
+        const size_t status_bytes = align_up(p->histogram_len * sizeof(unsigned long long), 256);
+        bytes = kControlBytes + status_bytes + 256;
+        hipError_t e = hipMalloc(&p->temp, bytes);
+        if (e != hipSuccess) {
+            delete p;
+            return fail(MRS_ERR_OUT_OF_MEMORY, "mrs_plan_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        }
+        p->control = static_cast<OnesweepControl*>(p->temp);
+        p->status = reinterpret_cast<unsigned long long*>(static_cast<char*>(p->temp) + kControlBytes);
+        p->error_flag = reinterpret_cast<uint32_t*>(static_cast<char*>(p->temp) + kControlBytes + status_bytes);
+        p->zero_bytes = kControlBytes + status_bytes;
+        e = hipMemset(p->temp, 0, bytes);
+        if (e != hipSuccess) {
+            (void)hipFree(p->temp);
+            delete p;
+            return fail(MRS_ERR_HIP, "mrs_plan_create: hipMemset failed: %s", hipGetErrorString(e));
+        }
+    }
+    p->temp_bytes = bytes;
+    *out = p;
+    return MRS_OK;
+}
+
+extern "C" int mrs_plan_destroy(mrs_plan* plan)
+{
+    clear_error();
+    if (!plan) return MRS_OK;
+    if (plan->temp) (void)hipFree(plan->temp);
+    delete plan;
+    return MRS_OK;
+}
+
+extern "C" int mrs_plan_get_info(const mrs_plan* plan, mrs_plan_info* info)
+{
+    clear_error();
+    if (!plan || !info) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_get_info: null argument");
+    info->num_passes = plan->num_passes;
+    info->radix = plan->radix;
+    info->tile_items = plan->tile_items;
+    info->threads = plan->threads;
+    info->max_tiles = plan->max_tiles;
+    info->histogram_len = plan->histogram_len;
+    info->temp_bytes = plan->temp_bytes;
+    return MRS_OK;
+}
+
+extern "C" int mrs_plan_check(mrs_plan* plan, void* stream)
+{
+    clear_error();
+    if (!plan) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_check: null plan");
+    if (int rc = check_device(plan->ctx, "mrs_plan_check")) return rc;
+    MRS_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (!plan->error_flag) return MRS_OK;
+    uint32_t flag = 0;
+    MRS_HIP_TRY(hipMemcpy(&flag, plan->error_flag, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) {
+        MRS_HIP_TRY(hipMemset(plan->error_flag, 0, sizeof flag));
+        return fail(MRS_ERR_DEVICE_TIMEOUT, "a chained-scan workgroup timed out waiting for its predecessor tile; "
+                                            "the output of that sort call is invalid");
+    }
+    return MRS_OK;
+}
+
+static int check_pair_buffers(const mrs_plan* plan, const void* ka, const void* va, const void* kb, const void* vb,
+                              const char* who)
+{
+    const size_t key_align = 4 * plan->desc.key_words;
+    if (!ka || !kb) return fail(MRS_ERR_INVALID_ARGUMENT, "%s: null key buffer", who);
+    if (misaligned(ka, key_align) || misaligned(kb, key_align))
+        return fail(MRS_ERR_INVALID_ARGUMENT, "%s: key buffers must be %zu-byte aligned", who, key_align);
+    if (plan->desc.payload_bytes) {
+        if (!va || !vb) return fail(MRS_ERR_INVALID_ARGUMENT, "%s: null payload buffer", who);
+        if (misaligned(va, plan->desc.payload_bytes) || misaligned(vb, plan->desc.payload_bytes))
+            return fail(MRS_ERR_INVALID_ARGUMENT, "%s: payload buffers must be %d-byte aligned", who,
+                        plan->desc.payload_bytes);
+    }
+    if (ka == kb || (va && va == vb)) return fail(MRS_ERR_INVALID_ARGUMENT, "%s: the A and B buffers must differ", who);
+    return MRS_OK;
+}
+
+extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b,
+                              void* stream, int* result_in_b)
+{
+    clear_error();
+    if (int rc = validate_call(plan, n, "mrs_sort_pairs")) return rc;
+    // result side by pass parity, src/main.rs:819-823
+    if (result_in_b) *result_in_b = (plan->num_passes % 2u) == 1u;
+    if (n == 0) return MRS_OK;
+    if (int rc = check_pair_buffers(plan, keys_a, vals_a, keys_b, vals_b, "mrs_sort_pairs")) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
+
+    if (plan->desc.algo == MRS_ALGO_ONESWEEP) {
+        const size_t zero = kControlBytes + align_up(static_cast<size_t>(num_tiles) * plan->radix * 8, 256);
+        MRS_HIP_TRY(hipMemsetAsync(plan->temp, 0, zero, s));
+        GlobalHistArgs h{};
+        h.keys = keys_a;
+        h.n = n32;
+        h.begin_bit = plan->desc.begin_bit;
+        h.end_bit = plan->desc.end_bit;
+        h.num_passes = plan->num_passes;
+        h.digit_map = nullptr;
+        h.map_mask = 0;
+        h.ghist = plan->control->ghist;
+        if (int rc = launch_global_hist(plan, h, s)) return rc;
+        if (int rc = launch_ghist_scan(plan, plan->num_passes, s)) return rc;
+    }
+
+    for (uint32_t pass = 0; pass < plan->num_passes; ++pass) {
+        const bool even = (pass % 2u) == 0u;  // ping-pong, src/main.rs:519-576
+        PassArgs a{};
+        a.keys_in = even ? keys_a : keys_b;
+        a.vals_in = even ? vals_a : vals_b;
+        a.keys_out = even ? keys_b : keys_a;
+        a.vals_out = even ? vals_b : vals_a;
+        a.n = n32;
+        a.num_tiles = num_tiles;
+        a.shift = pass_shift(plan, pass);
+        a.mask = pass_mask(plan, pass);
+        a.digit_map = nullptr;
+        if (plan->desc.algo == MRS_ALGO_THREE_KERNEL) {
+            // "Histogram calculation" / prefix sums / "Indexing", src/main.rs:595-664
+            if (int rc = launch_block_hist(plan, n32, a.keys_in, num_tiles, pass, plan->hist, s)) return rc;
+            if (int rc = launch_exclusive_scan(plan->hist, static_cast<uint64_t>(plan->radix) * num_tiles,
+                                               plan->scan_partials, s))
+                return rc;
+            a.scanned = plan->hist;
+            if (int rc = launch_pass(plan, kModeScatter, a, s)) return rc;
+        } else {
+            a.digit_base = plan->control->ghist + static_cast<size_t>(pass) * plan->radix;
+            a.status = plan->status;
+            a.tile_counter = &plan->control->tile_counter[pass];
+            a.error_flag = plan->error_flag;
+            a.tag = pass + 1;
+            if (int rc = launch_pass(plan, kModeOnesweep, a, s)) return rc;
+        }
+    }
+    return MRS_OK;
+}
+
+extern "C" int mrs_histogram(mrs_plan* plan, uint64_t n, const void* keys_dev, uint32_t pass, uint32_t* hist_dev,
+                             void* stream)
+{
+    clear_error();
+    if (int rc = validate_call(plan, n, "mrs_histogram")) return rc;
+    if (pass >= plan->num_passes) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_histogram: pass %u out of range", pass);
+    if (n == 0) return MRS_OK;
+    if (!keys_dev || !hist_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_histogram: null buffer");
+    const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
+    return launch_block_hist(plan, static_cast<uint32_t>(n), keys_dev, num_tiles, pass, hist_dev,
+                             static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mrs_scan(mrs_plan* plan, uint64_t n, uint32_t* hist_dev, void* stream)
+{
+    clear_error();
+    if (int rc = validate_call(plan, n, "mrs_scan")) return rc;
+    if (plan->desc.algo != MRS_ALGO_THREE_KERNEL)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_scan: the plan must be MRS_ALGO_THREE_KERNEL");
+    if (n == 0) return MRS_OK;
+    if (!hist_dev || misaligned(hist_dev, 16))
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_scan: the histogram must be a 16-byte aligned device pointer");
+    const uint64_t num_tiles = (n + plan->tile_items - 1) / plan->tile_items;
+    return launch_exclusive_scan(hist_dev, plan->radix * num_tiles, plan->scan_partials,
+                                 static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mrs_scatter(mrs_plan* plan, uint64_t n, const void* keys_in, const void* vals_in, void* keys_out,
+                           void* vals_out, const uint32_t* scanned_hist_dev, uint32_t pass, void* stream)
+{
+    clear_error();
+    if (int rc = validate_call(plan, n, "mrs_scatter")) return rc;
+    if (pass >= plan->num_passes) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_scatter: pass %u out of range", pass);
+    if (n == 0) return MRS_OK;
+    if (int rc = check_pair_buffers(plan, keys_in, vals_in, keys_out, vals_out, "mrs_scatter")) return rc;
+    if (!scanned_hist_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_scatter: null histogram");
+    PassArgs a{};
+    a.keys_in = keys_in;
+    a.vals_in = vals_in;
+    a.keys_out = keys_out;
+    a.vals_out = vals_out;
+    a.n = static_cast<uint32_t>(n);
+    a.num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
+    a.shift = pass_shift(plan, pass);
+    a.mask = pass_mask(plan, pass);
+    a.scanned = scanned_hist_dev;
+    return launch_pass(plan, kModeScatter, a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mrs_bucket_histogram(mrs_context* ctx, const void* keys_dev, uint64_t n, int32_t key_words,
+                                    uint32_t shift, uint32_t bits, uint64_t* counts_dev, void* stream)
+{
+    clear_error();
+    if (!ctx || !counts_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_bucket_histogram: null argument");
+    if (int rc = check_device(ctx, "mrs_bucket_histogram")) return rc;
+    if (key_words != 1 && key_words != 2) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_bucket_histogram: key_words");
+    if (bits == 0 || bits > 12 || shift + bits > 32u * key_words)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_bucket_histogram: need 1 <= bits <= 12 inside the key");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t bins = 1u << bits;
+    MRS_HIP_TRY(hipMemsetAsync(counts_dev, 0, bins * sizeof(uint64_t), s));
+    if (n == 0) return MRS_OK;
+    if (!keys_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_bucket_histogram: null keys");
+    uint64_t blocks = (n + 255) / 256;
+    const uint64_t cap = static_cast<uint64_t>(ctx->num_cus) * 8;
+    if (blocks > cap) blocks = cap;
+    unsigned long long* counts = reinterpret_cast<unsigned long long*>(counts_dev);
+    if (key_words == 1)
+        hipLaunchKernelGGL(bucket_histogram_kernel<uint32_t>, dim3(blocks), dim3(256), bins * 4, s,
+                           static_cast<const uint32_t*>(keys_dev), static_cast<unsigned long long>(n), shift, bins,
+                           counts);
+    else
+        hipLaunchKernelGGL(bucket_histogram_kernel<unsigned long long>, dim3(blocks), dim3(256), bins * 4, s,
+                           static_cast<const unsigned long long*>(keys_dev), static_cast<unsigned long long>(n), shift,
+                           bins, counts);
+    MRS_CHECK_LAUNCH("bucket_histogram_kernel");
+    return MRS_OK;
+}
+
+extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, const void* vals_in, void* keys_out,
+                             void* vals_out, uint32_t shift, uint32_t bits, const uint8_t* map_dev, uint32_t num_parts,
+                             uint32_t* part_counts_dev, void* stream)
+{
+    clear_error();
+    if (int rc = validate_call(plan, n, "mrs_partition")) return rc;
+    if (plan->desc.algo != MRS_ALGO_ONESWEEP)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_partition: the plan must be MRS_ALGO_ONESWEEP");
+    if (num_parts == 0 || num_parts > 16 || num_parts > plan->radix)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_partition: num_parts must be in [1, 16]");
+    if (bits == 0 || bits > 16 || shift + bits > 32u * plan->desc.key_words)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_partition: need 1 <= bits <= 16 inside the key");
+    if (!map_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_partition: null map");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        if (part_counts_dev) MRS_HIP_TRY(hipMemsetAsync(part_counts_dev, 0, 16 * sizeof(uint32_t), s));
+        return MRS_OK;
+    }
+    if (int rc = check_pair_buffers(plan, keys_in, vals_in, keys_out, vals_out, "mrs_partition")) return rc;
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
+    const size_t zero = kControlBytes + align_up(static_cast<size_t>(num_tiles) * plan->radix * 8, 256);
+    MRS_HIP_TRY(hipMemsetAsync(plan->temp, 0, zero, s));
+    GlobalHistArgs h{};
+    h.keys = keys_in;
+    h.n = n32;
+    h.begin_bit = shift;
+    h.end_bit = shift + bits;
+    h.num_passes = 1;
+    h.digit_map = map_dev;
+    h.map_mask = (1u << bits) - 1u;
+    h.ghist = plan->control->ghist;
+    if (int rc = launch_global_hist(plan, h, s)) return rc;
+    if (part_counts_dev) {
+        const size_t have = (plan->radix < 16 ? plan->radix : 16) * sizeof(uint32_t);
+        MRS_HIP_TRY(hipMemsetAsync(part_counts_dev, 0, 16 * sizeof(uint32_t), s));
+        MRS_HIP_TRY(hipMemcpyAsync(part_counts_dev, plan->control->ghist, have, hipMemcpyDeviceToDevice, s));
+    }
+    if (int rc = launch_ghist_scan(plan, 1, s)) return rc;
+    PassArgs a{};
+    a.keys_in = keys_in;
+    a.vals_in = vals_in;
+    a.keys_out = keys_out;
+    a.vals_out = vals_out;
+    a.n = n32;
+    a.num_tiles = num_tiles;
+    a.shift = shift;
+    a.mask = (1u << bits) - 1u;
+    a.digit_map = map_dev;
+    a.digit_base = plan->control->ghist;
+    a.status = plan->status;
+    a.tile_counter = &plan->control->tile_counter[0];
+    a.error_flag = plan->error_flag;
+    a.tag = 1;
+    return launch_pass(plan, kModeOnesweep, a, s);
+}

@@ -1,0 +1,121 @@
+// Internal declarations shared by the translation units of libmrs.so.
+#ifndef MRS_INTERNAL_H
+#define MRS_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "mrs.h"
+
+namespace mrs {
+
+// Records the calling thread's error message and returns `code`.
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+void clear_error();
+
+#define MRS_HIP_TRY(expr)                                                              \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return ::mrs::fail(MRS_ERR_HIP, "%s failed: %s (%s:%d)", #expr,            \
+                               hipGetErrorString(_e), __FILE__, __LINE__);             \
+    } while (0)
+
+// The launch itself can fail (bad configuration); report it instead of
+// leaving a sticky error behind.
+#define MRS_CHECK_LAUNCH(name)                                                         \
+    do {                                                                               \
+        hipError_t _e = hipGetLastError();                                             \
+        if (_e != hipSuccess)                                                          \
+            return ::mrs::fail(MRS_ERR_HIP, "launch of %s failed: %s", name,           \
+                               hipGetErrorString(_e));                                 \
+    } while (0)
+
+constexpr int kMaxPasses = 16;   // 64-bit keys with 4-bit digits
+constexpr int kMaxRadix = 256;
+
+// Per-launch arguments of a digit pass.
+struct PassArgs {
+    const void* keys_in;
+    const void* vals_in;
+    void* keys_out;
+    void* vals_out;
+    uint32_t n;
+    uint32_t num_tiles;
+    uint32_t shift;            // first bit of the digit
+    uint32_t mask;             // (1 << digit bits of this pass) - 1
+    const uint8_t* digit_map;  // optional: digit = digit_map[(key >> shift) & mask]
+    // three-kernel: scanned block histogram, digit-major [radix][num_tiles]
+    const uint32_t* scanned;
+    // onesweep
+    const uint32_t* digit_base;  // exclusive scan of the global digit histogram of this pass
+    unsigned long long* status;  // [num_tiles][radix] tile status words
+    uint32_t* tile_counter;      // ticket dispenser of this pass
+    uint32_t* error_flag;
+    uint32_t tag;                // pass tag stored in the status words (never 0)
+};
+
+// Control block at the start of a onesweep plan's temporary memory; zeroed by
+// one memset per sort call together with the status words that follow it.
+struct OnesweepControl {
+    uint32_t ghist[kMaxPasses * kMaxRadix];  // global digit histograms, then their scans
+    uint32_t tile_counter[kMaxPasses];
+};
+static_assert(sizeof(OnesweepControl) % 16 == 0, "memset block must be a multiple of 16 bytes");
+
+struct KernelConfig {
+    int threads;
+    int kpt;  // keys per thread
+};
+
+}  // namespace mrs
+
+struct mrs_context {
+    int device;
+    int num_cus;
+};
+
+struct mrs_plan {
+    mrs_context* ctx;
+    mrs_plan_desc desc;
+    uint32_t radix_bits, radix, num_passes;
+    uint32_t threads, kpt, tile_items;
+    uint64_t max_tiles;
+    uint64_t histogram_len;
+    // device memory owned by the plan
+    void* temp;
+    size_t temp_bytes;
+    // three-kernel
+    uint32_t* hist;          // [radix][max_tiles]
+    uint32_t* scan_partials; // chunk sums of the scan
+    uint64_t scan_partials_len;
+    // onesweep
+    mrs::OnesweepControl* control;
+    unsigned long long* status;  // [max_tiles][radix]
+    size_t zero_bytes;           // control + status, cleared per call
+    uint32_t* error_flag;        // sticky device word
+};
+
+namespace mrs {
+
+// radix kernels (mrs_radix.hip)
+int launch_block_histogram(const mrs_plan* plan, uint32_t n, const void* keys, uint32_t shift,
+                           uint32_t mask, uint32_t* hist, hipStream_t s);
+int launch_scatter(const mrs_plan* plan, const PassArgs& a, hipStream_t s);
+int launch_global_histogram(const mrs_plan* plan, uint32_t n, const void* keys,
+                            const uint8_t* digit_map, uint32_t map_shift, uint32_t map_mask,
+                            uint32_t* ghist, hipStream_t s);
+int launch_onesweep_pass(const mrs_plan* plan, const PassArgs& a, hipStream_t s);
+bool config_supported(int key_words, int payload_bytes, int digit_bits, int tile_items,
+                      int algo, KernelConfig* cfg);
+
+// scan (mrs_scan.hip)
+uint64_t scan_partials_len(uint64_t len);
+int launch_exclusive_scan(uint32_t* vals, uint64_t len, uint32_t* partials, hipStream_t s);
+
+}  // namespace mrs
+
+#endif

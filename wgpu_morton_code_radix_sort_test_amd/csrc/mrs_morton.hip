@@ -1,0 +1,280 @@
+// Morton encoders and the synthetic input generators.
+//
+// Built with -ffp-contract=off: the f32 expressions below are evaluated one
+// IEEE operation at a time, as the CPU checker does.
+#include "mrs_internal.h"
+
+namespace mrs {
+
+// ---- extended Morton code from the LUT blob --------------------------------------
+// One thread per triangle.  The reference's morton_code_unrolled gives each
+// thread eight consecutive triangles of one of eight slices
+// (src/shaders/morton_code.wgsl:96-99); the per-item arithmetic
+// (src/shaders/morton_code.wgsl:103-127) is what is kept here.
+//
+// The 18 KiB coordinate table is copied into LDS once per workgroup (the
+// reference's README notes the pass was limited by the table lookups); the
+// 32 KiB size table is read once per triangle and stays in global memory/L2.
+constexpr int kLutWords = 4608;
+constexpr int kEncodeThreads = 256;
+
+// f32 -> u32 toward zero; NaN and negatives give 0, values >= 2^32 give 2^32-1.
+__device__ __forceinline__ uint32_t f2u_sat(float f)
+{
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return static_cast<uint32_t>(f);
+}
+
+struct MortonUniformsTail {  // byte offsets inside the blob, src/shaders/morton_code.wgsl:19-26
+    static constexpr int kSizeLut = 18432;
+    static constexpr int kOffset = 51216;
+    static constexpr int kSizeMultiplier = 51228;
+    static constexpr int kMultiplier = 51232;
+};
+
+__global__ __launch_bounds__(kEncodeThreads) void morton_encode_lut_kernel(
+    const unsigned char* __restrict__ blob, const unsigned char* __restrict__ vertices,
+    unsigned long long num_vertices, const uint4* __restrict__ triangles, unsigned long long n,
+    uint2* __restrict__ codes)
+{
+    __shared__ uint32_t s_lut[kLutWords];
+    const uint4* lut4 = reinterpret_cast<const uint4*>(blob);
+    for (int j = threadIdx.x; j < kLutWords / 4; j += kEncodeThreads)
+        reinterpret_cast<uint4*>(s_lut)[j] = lut4[j];
+    __syncthreads();
+
+    const uint32_t* __restrict__ size_lut = reinterpret_cast<const uint32_t*>(blob + MortonUniformsTail::kSizeLut);
+    const float* offset = reinterpret_cast<const float*>(blob + MortonUniformsTail::kOffset);
+    const float* multiplier = reinterpret_cast<const float*>(blob + MortonUniformsTail::kMultiplier);
+    const float size_multiplier = *reinterpret_cast<const float*>(blob + MortonUniformsTail::kSizeMultiplier);
+
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * kEncodeThreads;
+    for (unsigned long long t = static_cast<unsigned long long>(blockIdx.x) * kEncodeThreads + threadIdx.x; t < n;
+         t += stride) {
+        const uint4 tri = triangles[t];
+        float v[3][3];
+        const uint32_t vi[3] = {tri.x, tri.y, tri.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            // wgpu clamps out-of-range indices (robust buffer access); a vertex
+            // index past the buffer reads the last vertex here
+            unsigned long long idx = vi[k] < num_vertices ? vi[k] : num_vertices - 1;
+            const float* p = reinterpret_cast<const float*>(vertices + idx * MRS_VERTEX_STRIDE);
+            v[k][0] = p[0]; v[k][1] = p[1]; v[k][2] = p[2];
+        }
+        uint32_t p[3];
+        float d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float mn = fminf(fminf(v[0][c], v[1][c]), v[2][c]);
+            const float mx = fmaxf(fmaxf(v[0][c], v[1][c]), v[2][c]);
+            const float centre = (mn + mx) * 0.5f;
+            p[c] = f2u_sat((centre - offset[c]) * multiplier[c] - 0.001f);
+            d[c] = mx - mn;
+        }
+        // sqrtf is correctly rounded under -fhip-fp32-correctly-rounded-divide-sqrt; __fsqrt_rn is the
+        // 1-ulp hardware instruction
+        const float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        uint32_t j = f2u_sat(len * size_multiplier);
+        j = j > 4095u ? 4095u : j;  // the size table has 4096 entries
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                // shift by i*3, as written at src/shaders/morton_code.wgsl:113-115
+                const uint32_t byte = (p[c] >> (3 * i)) & 0xFFu;
+                const uint2 e = *reinterpret_cast<const uint2*>(&s_lut[(c + 3 * i) * 512 + byte * 2]);
+                lo |= e.x;
+                hi |= e.y;
+            }
+        }
+        const uint2 s = *reinterpret_cast<const uint2*>(&size_lut[j * 2]);
+        codes[t] = make_uint2(lo | s.x, hi | s.y);
+    }
+}
+
+// ---- 30-bit Morton key of a point -----------------------------------------------------
+__device__ __forceinline__ uint32_t spread10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+struct Bounds3 {
+    float mn[3];
+    float mx[3];
+};
+
+// Each thread encodes 4 consecutive points = 48 bytes = three 16-byte loads.
+__global__ __launch_bounds__(256) void morton_encode30_kernel(const float* __restrict__ xyz, unsigned long long n,
+                                                               const Bounds3 b, uint32_t* __restrict__ keys,
+                                                               uint32_t* __restrict__ idx)
+{
+    const float ext[3] = {b.mx[0] - b.mn[0], b.mx[1] - b.mn[1], b.mx[2] - b.mn[2]};
+    const unsigned long long groups = (n + 3) / 4;
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256;
+    for (unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * 256 + threadIdx.x; g < groups;
+         g += stride) {
+        const unsigned long long first = g * 4;
+        float f[12];
+        if (first + 4 <= n) {
+            const float4* p = reinterpret_cast<const float4*>(xyz + first * 3);
+            const float4 a0 = p[0], a1 = p[1], a2 = p[2];
+            f[0] = a0.x; f[1] = a0.y; f[2] = a0.z; f[3] = a0.w;
+            f[4] = a1.x; f[5] = a1.y; f[6] = a1.z; f[7] = a1.w;
+            f[8] = a2.x; f[9] = a2.y; f[10] = a2.z; f[11] = a2.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) f[j] = first * 3 + j < n * 3 ? xyz[first * 3 + j] : 0.0f;
+        }
+        uint32_t k[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t u[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float t = (f[3 * q + c] - b.mn[c]) / ext[c];
+                u[c] = f2u_sat(fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f));
+            }
+            k[q] = (spread10(u[0]) << 2) | (spread10(u[1]) << 1) | spread10(u[2]);
+        }
+        if (first + 4 <= n) {
+            *reinterpret_cast<uint4*>(keys + first) = make_uint4(k[0], k[1], k[2], k[3]);
+            const uint32_t i0 = static_cast<uint32_t>(first);
+            *reinterpret_cast<uint4*>(idx + first) = make_uint4(i0, i0 + 1, i0 + 2, i0 + 3);
+        } else {
+            for (int q = 0; q < 4; ++q)
+                if (first + q < n) {
+                    keys[first + q] = k[q];
+                    idx[first + q] = static_cast<uint32_t>(first + q);
+                }
+        }
+    }
+}
+
+// ---- generators: splitmix64-style counter hash -------------------------------------------
+__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+__host__ __device__ __forceinline__ uint32_t rand_u32(unsigned long long stream_key, unsigned long long index)
+{
+    return static_cast<uint32_t>(mix64(stream_key + 0x9E3779B97F4A7C15ull * (index + 1ull)) >> 32);
+}
+
+__global__ __launch_bounds__(256) void generate_points_kernel(unsigned long long k0, unsigned long long k1,
+                                                               unsigned long long k2, unsigned long long n,
+                                                               float* __restrict__ xyz)
+{
+    const unsigned long long total = n * 3;
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256;
+    for (unsigned long long j = static_cast<unsigned long long>(blockIdx.x) * 256 + threadIdx.x; j < total;
+         j += stride) {
+        const unsigned long long i = j / 3;
+        const int c = static_cast<int>(j - i * 3);
+        const unsigned long long key = c == 0 ? k0 : (c == 1 ? k1 : k2);
+        xyz[j] = static_cast<float>(rand_u32(key, i) >> 8) * (1.0f / 16777216.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void generate_u32_kernel(unsigned long long key, unsigned long long n,
+                                                            uint32_t* __restrict__ out)
+{
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256;
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride)
+        out[i] = rand_u32(key, i);
+}
+
+static unsigned grid_for(unsigned long long work_items, int num_cus)
+{
+    unsigned long long blocks = (work_items + 255) / 256;
+    const unsigned long long cap = static_cast<unsigned long long>(num_cus) * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return static_cast<unsigned>(blocks);
+}
+
+}  // namespace mrs
+
+using namespace mrs;
+
+extern "C" int mrs_morton_encode_lut(mrs_context* ctx, const void* uniforms_dev, const void* vertices_dev,
+                                     uint64_t num_vertices, const void* triangles_dev, uint64_t n,
+                                     uint32_t* codes_dev, void* stream)
+{
+    clear_error();
+    if (!ctx) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode_lut: null context");
+    if (n == 0) return MRS_OK;
+    if (!uniforms_dev || !vertices_dev || !triangles_dev || !codes_dev)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode_lut: null buffer");
+    if (num_vertices == 0) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode_lut: no vertices");
+    if ((reinterpret_cast<uintptr_t>(uniforms_dev) | reinterpret_cast<uintptr_t>(triangles_dev)) & 15u)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode_lut: uniforms and triangles must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(codes_dev) & 7u) || (reinterpret_cast<uintptr_t>(vertices_dev) & 3u))
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode_lut: misaligned codes or vertices");
+    hipLaunchKernelGGL(morton_encode_lut_kernel, dim3(grid_for(n, ctx->num_cus)), dim3(kEncodeThreads), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const unsigned char*>(uniforms_dev),
+                       static_cast<const unsigned char*>(vertices_dev), static_cast<unsigned long long>(num_vertices),
+                       static_cast<const uint4*>(triangles_dev), static_cast<unsigned long long>(n),
+                       reinterpret_cast<uint2*>(codes_dev));
+    MRS_CHECK_LAUNCH("morton_encode_lut_kernel");
+    return MRS_OK;
+}
+
+extern "C" int mrs_morton_encode30(mrs_context* ctx, const float* xyz_dev, uint64_t n, const float* mn,
+                                   const float* mx, uint32_t* keys_dev, uint32_t* idx_dev, void* stream)
+{
+    clear_error();
+    if (!ctx) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30: null context");
+    if (n == 0) return MRS_OK;
+    if (n > 0xFFFFFFFFull) return fail(MRS_ERR_UNSUPPORTED, "mrs_morton_encode30: n must fit in 32 bits");
+    if (!xyz_dev || !mn || !mx || !keys_dev || !idx_dev)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30: null pointer");
+    if ((reinterpret_cast<uintptr_t>(xyz_dev) | reinterpret_cast<uintptr_t>(keys_dev) |
+         reinterpret_cast<uintptr_t>(idx_dev)) & 15u)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30: buffers must be 16-byte aligned");
+    Bounds3 b;
+    for (int c = 0; c < 3; ++c) { b.mn[c] = mn[c]; b.mx[c] = mx[c]; }
+    hipLaunchKernelGGL(morton_encode30_kernel, dim3(grid_for((n + 3) / 4, ctx->num_cus)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), xyz_dev, static_cast<unsigned long long>(n), b, keys_dev,
+                       idx_dev);
+    MRS_CHECK_LAUNCH("morton_encode30_kernel");
+    return MRS_OK;
+}
+
+extern "C" int mrs_generate_points(mrs_context* ctx, uint64_t seed, uint64_t n, float* xyz_dev, void* stream)
+{
+    clear_error();
+    if (!ctx) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_generate_points: null context");
+    if (n == 0) return MRS_OK;
+    if (!xyz_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_generate_points: null buffer");
+    unsigned long long k[3];
+    for (unsigned long long c = 0; c < 3; ++c) k[c] = mix64(seed + 0x9E3779B97F4A7C15ull * (c + 1ull));
+    hipLaunchKernelGGL(generate_points_kernel, dim3(grid_for(n * 3, ctx->num_cus)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), k[0], k[1], k[2], static_cast<unsigned long long>(n), xyz_dev);
+    MRS_CHECK_LAUNCH("generate_points_kernel");
+    return MRS_OK;
+}
+
+extern "C" int mrs_generate_u32(mrs_context* ctx, uint64_t seed, uint64_t stream_id, uint64_t n, uint32_t* out_dev,
+                                void* stream)
+{
+    clear_error();
+    if (!ctx) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_generate_u32: null context");
+    if (n == 0) return MRS_OK;
+    if (!out_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_generate_u32: null buffer");
+    const unsigned long long key = mix64(seed + 0x9E3779B97F4A7C15ull * (stream_id + 1ull));
+    hipLaunchKernelGGL(generate_u32_kernel, dim3(grid_for(n, ctx->num_cus)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), key, static_cast<unsigned long long>(n), out_dev);
+    MRS_CHECK_LAUNCH("generate_u32_kernel");
+    return MRS_OK;
+}
