@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Benchmark of the Morton-key radix sort hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one sort of the resident batch: 2^28 (30-bit Morton key, u32 index)
+pairs per GPU, 8-bit digits, onesweep passes, full 32 key bits.  Inputs are
+synthetic: points from the library's counter-based generator (seed 7) encoded to
+Morton keys on the GPU before the timed region.  Every step sorts a FRESH
+unsorted buffer from a pool built beforehand (sorting mutates its input, and
+re-sorting sorted data would be a different workload), so the timed region
+holds nothing but the K sorts.
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) a step is the
+distributed sort of N * 2^28 pairs: top-bits histogram, RCCL all-reduce, bucket
+-> rank split, local partition, all-to-all-v exchange over xGMI, local sort.
+
+Rank 0 prints one JSON line.  `value` is whole-job Gkeys/s.  `roofline` is for
+the dominant kernel (one onesweep digit pass: 16 algorithmic bytes per pair per
+launch) timed with HIP events on the launch stream; `cpu_baseline` is std::sort
+on a bounded sample on the host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import wgpu_morton_code_radix_sort_test_amd as mrs  # noqa: E402
+
+HBM_PEAK_BYTES_PER_S = 8.0e12          # MI355X HBM3E peak
+SORT_BYTES_PER_PAIR = 68.0             # 4 (key read for histograms) + 4 passes * (8 read + 8 write)
+PASS_BYTES_PER_PAIR = 16.0             # one digit pass: read key+index, write key+index
+SEED = 7
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=28, help="pairs per GPU = 2^log2n")
+    ap.add_argument("--algo", default="onesweep", choices=["onesweep", "three_kernel"])
+    ap.add_argument("--digit-bits", type=int, default=8)
+    ap.add_argument("--tile-items", type=int, default=0)
+    ap.add_argument("--pool", type=int, default=0, help="distinct unsorted inputs (0 = steps + warmup, capped by memory)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log2", type=int, default=25)
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def make_input(ctx, n, seed):
+    """points -> (keys, idx) on the device; returns the two tensors."""
+    xyz = ctx.generate_points(seed, n)
+    mn = xyz.amin(dim=0).cpu().numpy()
+    mx = xyz.amax(dim=0).cpu().numpy()
+    keys, idx = ctx.morton_encode30(xyz, mn, mx)
+    del xyz
+    return keys, idx
+
+
+def verify_sorted(keys, idx, ref_keys_unsorted):
+    """Size-independent checks on the device: non-decreasing keys, stable ties, a permutation
+    whose gathered input keys equal the output keys."""
+    k = keys.to(torch.int64) & 0xFFFFFFFF
+    i = idx.to(torch.int64) & 0xFFFFFFFF
+    dk = k[1:] - k[:-1]
+    ok_sorted = bool((dk >= 0).all())
+    ok_stable = bool(((dk > 0) | (i[1:] > i[:-1])).all())
+    gathered = ref_keys_unsorted[i]
+    ok_perm = bool((gathered == keys).all())
+    return ok_sorted and ok_stable and ok_perm
+
+
+def cpu_baseline(sample_keys, sample_idx):
+    """std::sort on the host (oracle/cpu_sort.cpp): single thread and all usable cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    cs = oracle_lib.CpuSort()
+    hw = cs.hardware_threads()
+    threads = max(1, min(hw, int(os.environ.get("OMP_NUM_THREADS", hw))))
+    n = sample_keys.size
+    k1, i1 = sample_keys.copy(), sample_idx.copy()
+    secs_par, used = cs.sort_pairs(k1, i1, threads)
+    n_single = max(1, n // 4)
+    k2, i2 = sample_keys[:n_single].copy(), sample_idx[:n_single].copy()
+    secs_one, _ = cs.sort_pairs(k2, i2, 1)
+    return {
+        "value": n / secs_par / 1e9,
+        "unit": "Gkeys/s",
+        "cores": used,
+        "kind": "port",
+        "sample": f"std::sort (__gnu_parallel, {used} threads) of the first 2^{int(np.log2(n))} (key,index) pairs of the "
+                  f"step input, packed as u64; single-thread std::sort on 2^{int(np.log2(n_single))} pairs: "
+                  f"{n_single / secs_one / 1e9:.4f} Gkeys/s; host reports {hw} hardware threads",
+        "single_thread_gkeys_per_s": n_single / secs_one / 1e9,
+    }, k1, i1
+
+
+def load_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC run, if present."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                return json.load(f)
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the sort has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = mrs.Context(local_rank)
+    n = 1 << args.log2n
+    algo = mrs.ALGO_ONESWEEP if args.algo == "onesweep" else mrs.ALGO_THREE_KERNEL
+
+    total_steps = args.steps + args.warmup
+    free_b, _ = torch.cuda.mem_get_info()
+    per_input = 8 * n
+    budget = int(free_b * 0.6) - 4 * per_input
+    pool = args.pool or total_steps
+    pool = max(1, min(pool, max(1, budget // per_input)))
+
+    if distributed:
+        from wgpu_morton_code_radix_sort_test_amd.dist import DistributedSorter
+
+        sorter = DistributedSorter(ctx, n, world, rank, digit_bits=args.digit_bits)
+        inputs = [make_input(ctx, n, SEED + 1000 * rank + j) for j in range(pool)]
+        # payload = global index
+        for k, i in inputs:
+            i += rank * n
+
+        def step(j):
+            k, i = inputs[j % pool]
+            return sorter.sort(k, i)
+    else:
+        plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=args.digit_bits, algo=algo,
+                            tile_items=args.tile_items)
+        inputs = [make_input(ctx, n, SEED + j) for j in range(pool)]
+        kb = torch.empty(n, dtype=torch.int32, device=ctx.device)
+        vb = torch.empty(n, dtype=torch.int32, device=ctx.device)
+        restore = pool < total_steps
+        if restore:
+            pristine = [(k.clone(), i.clone()) for k, i in inputs[:1]]
+
+        def step(j):
+            k, i = inputs[j % pool]
+            if restore and j >= pool:
+                # the pool is smaller than the run: put unsorted data back (inside the timed region)
+                k.copy_(pristine[0][0])
+                i.copy_(pristine[0][1])
+            in_b = plan.sort_pairs(k, i, kb, vb)
+            return (kb, vb) if in_b else (k, i)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for j in range(args.warmup):
+        step(j)
+    barrier()
+    t0 = time.perf_counter()
+    for j in range(args.warmup, total_steps):
+        out = step(j)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    total_pairs = n * world
+    value = total_pairs / (elapsed / args.steps) / 1e9
+
+    # ---- correctness of what was just timed (size-independent properties) -------------------
+    verified = None
+    if not args.no_verify and not distributed:
+        ref_keys, _ = make_input(ctx, n, SEED + ((total_steps - 1) % pool)) if not (restore and total_steps > pool) \
+            else (pristine[0][0], None)
+        plan.check()
+        verified = verify_sorted(out[0], out[1], ref_keys)
+        del ref_keys
+        if not verified:
+            raise SystemExit("bench.py: the sorted output failed verification")
+    elif distributed and not args.no_verify:
+        verified = sorter.verify(out[0], out[1])
+        if not verified:
+            raise SystemExit("bench.py: the distributed output failed verification")
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream ----------------------
+    roofline = None
+    extra = {}
+    if not distributed and algo == mrs.ALGO_ONESWEEP:
+        plan.set_timing(True)
+        pass_ms, hist_ms, sort_ms = [], [], []
+        fresh = [make_input(ctx, n, SEED + 500 + j) for j in range(3)]
+        for k, i in fresh:
+            plan.sort_pairs(k, i, kb, vb)
+            tm = plan.timings()
+            pass_ms += [ms for lab, ms in tm if lab == "onesweep_pass"]
+            hist_ms += [ms for lab, ms in tm if lab == "global_histogram"]
+            sort_ms.append(sum(ms for _, ms in tm))
+        plan.set_timing(False)
+        del fresh
+        avg_pass = float(np.mean(pass_ms)) * 1e-3
+        achieved = PASS_BYTES_PER_PAIR * n / avg_pass / 1e9
+        traffic = load_traffic()
+        roofline = {
+            "bound": "hbm",
+            "kernel": "digit_pass_kernel<onesweep>",
+            "achieved": achieved,
+            "peak": HBM_PEAK_BYTES_PER_S / 1e9,
+            "unit": "GB/s",
+            "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S,
+            "traffic": traffic.get("bytes_per_launch") if traffic else None,
+            "algorithmic_bytes_per_launch": PASS_BYTES_PER_PAIR * n,
+            "avg_launch_ms": avg_pass * 1e3,
+        }
+        extra = {
+            "per_pass_ms": [round(float(x), 4) for x in pass_ms[-plan.info.num_passes:]],
+            "global_histogram_ms": round(float(np.mean(hist_ms)), 4),
+            "global_histogram_GBps": 4.0 * n / (float(np.mean(hist_ms)) * 1e-3) / 1e9,
+            "sort_event_ms": round(float(np.mean(sort_ms)), 4),
+            "sort_roofline_frac_68B": SORT_BYTES_PER_PAIR * n / (float(np.mean(sort_ms)) * 1e-3) / HBM_PEAK_BYTES_PER_S,
+        }
+        # Morton encode, reported separately: 12 B read + 8 B written per point
+        xyz = ctx.generate_points(SEED, n)
+        mn, mx = xyz.amin(dim=0).cpu().numpy(), xyz.amax(dim=0).cpu().numpy()
+        ek, ei = ctx.morton_encode30(xyz, mn, mx)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ctx.morton_encode30(xyz, mn, mx, ek, ei)
+        e1.record()
+        torch.cuda.synchronize()
+        enc_ms = e0.elapsed_time(e1) / 5
+        extra["morton_encode30_ms"] = round(enc_ms, 4)
+        extra["morton_encode30_GBps"] = 20.0 * n / (enc_ms * 1e-3) / 1e9
+        del xyz, ek, ei
+
+    cpu = None
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        m = min(n, 1 << args.cpu_sample_log2)
+        sk, si = make_input(ctx, n, SEED + ((total_steps - 1) % pool)) if not (restore and total_steps > pool) \
+            else pristine[0]
+        sample_k = sk[:m].cpu().numpy().view(np.uint32)
+        sample_i = si[:m].cpu().numpy().view(np.uint32)
+        cpu, _, _ = cpu_baseline(sample_k, sample_i)
+
+    if rank == 0:
+        line = {
+            "metric": "Gkeys/s sorted (u32 Morton key + u32 payload)",
+            "value": value,
+            "unit": "Gkeys/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"2^{args.log2n} (30-bit Morton key, u32 index) pairs per GPU from uniform random 3D points, "
+                            f"{args.digit_bits}-bit digits over all 32 key bits, {args.algo}",
+                "pairs_per_gpu": n,
+                "total_pairs": total_pairs,
+                "digit_bits": args.digit_bits,
+                "algo": args.algo,
+                "distinct_inputs": pool,
+                "parallelism": f"{world} x MI355X, sharded by top-digit bucket" if distributed else "1 x MI355X",
+            },
+            "verified": verified,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        if distributed:
+            line.update(sorter.last_breakdown())
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

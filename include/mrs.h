@@ -103,6 +103,17 @@ int mrs_plan_get_info(const mrs_plan* plan, mrs_plan_info* info);
  * tests and harnesses; not needed on the hot path. */
 int mrs_plan_check(mrs_plan* plan, void* stream);
 
+/* Measurement hook (the reference has no timers; its passes are named for an
+ * external profiler, src/main.rs:583-662).  With timing enabled, mrs_sort_pairs
+ * records a HIP event on the caller's stream before its first launch and after
+ * every launch.  mrs_plan_get_timings synchronises on the last event and
+ * returns, for each launch of the most recent mrs_sort_pairs call, its
+ * duration in milliseconds and a label of at most 31 characters
+ * ("memset", "global_histogram", "histogram_scan", "onesweep_pass",
+ * "block_histogram", "scan", "scatter").  labels_out holds cap * 32 bytes. */
+int mrs_plan_set_timing(mrs_plan* plan, int enable);
+int mrs_plan_get_timings(mrs_plan* plan, int cap, float* ms_out, char* labels_out, int* count_out);
+
 /* ---- Morton encode ------------------------------------------------------- */
 /* Replaces the "Morton Coding" dispatch of morton_code_unrolled
  * (src/main.rs:581-592, src/shaders/morton_code.wgsl:90-335).  Buffers have the

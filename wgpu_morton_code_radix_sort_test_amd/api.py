@@ -230,6 +230,22 @@ class SortPlan:
         )
         return counts
 
+    def set_timing(self, enable=True):
+        _lib.check(self.lib.mrs_plan_set_timing(self._h, 1 if enable else 0))
+
+    def timings(self):
+        """[(label, milliseconds)] for every launch of the last sort_pairs call (timing must be on)."""
+        cap = 96
+        ms = (ctypes.c_float * cap)()
+        labels = ctypes.create_string_buffer(32 * cap)
+        count = ctypes.c_int(0)
+        _lib.check(self.lib.mrs_plan_get_timings(self._h, cap, ms, labels, ctypes.byref(count)))
+        out = []
+        for i in range(count.value):
+            raw = labels.raw[32 * i: 32 * i + 32]
+            out.append((raw.split(b"\0", 1)[0].decode(), float(ms[i])))
+        return out
+
     def check(self, stream=None):
         """Synchronises and raises MrsError if a look-back timed out on the device."""
         _lib.check(self.lib.mrs_plan_check(self._h, _stream(stream)))

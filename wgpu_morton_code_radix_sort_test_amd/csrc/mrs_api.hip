@@ -132,6 +132,18 @@ static int validate_call(const mrs_plan* plan, uint64_t n, const char* who)
     return check_device(plan->ctx, who);
 }
 
+// Records a timing mark after the launch called `label` (no-op unless timing is on).
+static int mark(mrs_plan* p, const char* label, hipStream_t s)
+{
+    if (!p->timing) return MRS_OK;
+    const int cap = static_cast<int>(sizeof(p->marks) / sizeof(p->marks[0]));
+    if (p->num_marks >= cap) return MRS_OK;
+    MRS_HIP_TRY(hipEventRecord(p->marks[p->num_marks], s));
+    p->mark_labels[p->num_marks] = label;
+    p->num_marks++;
+    return MRS_OK;
+}
+
 static bool misaligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; }
 
 // ---- bucket histogram (multi-GPU split) ---------------------------------------------
@@ -267,6 +279,10 @@ extern "C" int mrs_plan_destroy(mrs_plan* plan)
 {
     clear_error();
     if (!plan) return MRS_OK;
+    if (plan->timing) {
+        const int cap = static_cast<int>(sizeof(plan->marks) / sizeof(plan->marks[0]));
+        for (int i = 0; i < cap; ++i) (void)hipEventDestroy(plan->marks[i]);
+    }
     if (plan->temp) (void)hipFree(plan->temp);
     delete plan;
     return MRS_OK;
@@ -333,9 +349,12 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
 
+    plan->num_marks = 0;
+    if (int rc = mark(plan, "start", s)) return rc;
     if (plan->desc.algo == MRS_ALGO_ONESWEEP) {
         const size_t zero = kControlBytes + align_up(static_cast<size_t>(num_tiles) * plan->radix * 8, 256);
         MRS_HIP_TRY(hipMemsetAsync(plan->temp, 0, zero, s));
+        if (int rc = mark(plan, "memset", s)) return rc;
         GlobalHistArgs h{};
         h.keys = keys_a;
         h.n = n32;
@@ -346,7 +365,9 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
         h.map_mask = 0;
         h.ghist = plan->control->ghist;
         if (int rc = launch_global_hist(plan, h, s)) return rc;
+        if (int rc = mark(plan, "global_histogram", s)) return rc;
         if (int rc = launch_ghist_scan(plan, plan->num_passes, s)) return rc;
+        if (int rc = mark(plan, "histogram_scan", s)) return rc;
     }
 
     for (uint32_t pass = 0; pass < plan->num_passes; ++pass) {
@@ -364,11 +385,14 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
         if (plan->desc.algo == MRS_ALGO_THREE_KERNEL) {
             // "Histogram calculation" / prefix sums / "Indexing", src/main.rs:595-664
             if (int rc = launch_block_hist(plan, n32, a.keys_in, num_tiles, pass, plan->hist, s)) return rc;
+            if (int rc = mark(plan, "block_histogram", s)) return rc;
             if (int rc = launch_exclusive_scan(plan->hist, static_cast<uint64_t>(plan->radix) * num_tiles,
                                                plan->scan_partials, s))
                 return rc;
+            if (int rc = mark(plan, "scan", s)) return rc;
             a.scanned = plan->hist;
             if (int rc = launch_pass(plan, kModeScatter, a, s)) return rc;
+            if (int rc = mark(plan, "scatter", s)) return rc;
         } else {
             a.digit_base = plan->control->ghist + static_cast<size_t>(pass) * plan->radix;
             a.status = plan->status;
@@ -376,8 +400,48 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
             a.error_flag = plan->error_flag;
             a.tag = pass + 1;
             if (int rc = launch_pass(plan, kModeOnesweep, a, s)) return rc;
+            if (int rc = mark(plan, "onesweep_pass", s)) return rc;
         }
     }
+    return MRS_OK;
+}
+
+extern "C" int mrs_plan_set_timing(mrs_plan* plan, int enable)
+{
+    clear_error();
+    if (!plan) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_set_timing: null plan");
+    if (int rc = check_device(plan->ctx, "mrs_plan_set_timing")) return rc;
+    const int cap = static_cast<int>(sizeof(plan->marks) / sizeof(plan->marks[0]));
+    if (enable && !plan->timing) {
+        for (int i = 0; i < cap; ++i) MRS_HIP_TRY(hipEventCreate(&plan->marks[i]));
+        plan->timing = true;
+        plan->num_marks = 0;
+    } else if (!enable && plan->timing) {
+        for (int i = 0; i < cap; ++i) (void)hipEventDestroy(plan->marks[i]);
+        plan->timing = false;
+        plan->num_marks = 0;
+    }
+    return MRS_OK;
+}
+
+extern "C" int mrs_plan_get_timings(mrs_plan* plan, int cap, float* ms_out, char* labels_out, int* count_out)
+{
+    clear_error();
+    if (!plan || !ms_out || !labels_out || !count_out)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_get_timings: null argument");
+    *count_out = 0;
+    if (!plan->timing) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_get_timings: timing is not enabled");
+    if (plan->num_marks < 2) return MRS_OK;
+    MRS_HIP_TRY(hipEventSynchronize(plan->marks[plan->num_marks - 1]));
+    int count = 0;
+    for (int i = 1; i < plan->num_marks && count < cap; ++i) {
+        float ms = 0.f;
+        MRS_HIP_TRY(hipEventElapsedTime(&ms, plan->marks[i - 1], plan->marks[i]));
+        ms_out[count] = ms;
+        std::snprintf(labels_out + 32 * count, 32, "%s", plan->mark_labels[i]);
+        ++count;
+    }
+    *count_out = count;
     return MRS_OK;
 }
 

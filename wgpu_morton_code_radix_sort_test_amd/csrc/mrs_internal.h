@@ -97,6 +97,12 @@ struct mrs_plan {
     unsigned long long* status;  // [max_tiles][radix]
     size_t zero_bytes;           // control + status, cleared per call
     uint32_t* error_flag;        // sticky device word
+    // optional per-launch timing (mrs_plan_set_timing): events recorded on the
+    // caller's stream around every launch of the last mrs_sort_pairs call
+    bool timing;
+    int num_marks;
+    hipEvent_t marks[mrs::kMaxPasses * 4 + 8];
+    const char* mark_labels[mrs::kMaxPasses * 4 + 8];
 };
 
 namespace mrs {
