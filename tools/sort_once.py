@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Runs a few sorts of 2^log2n Morton (key, index) pairs and prints per-launch event times.
+
+A small driver for profiling (rocprofv3 --kernel-trace / --pmc) and A/B tuning.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import wgpu_morton_code_radix_sort_test_amd as mrs  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2n", type=int, default=28)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--tile-items", type=int, default=0)
+    ap.add_argument("--digit-bits", type=int, default=8)
+    ap.add_argument("--algo", default="onesweep")
+    ap.add_argument("--key-words", type=int, default=1)
+    ap.add_argument("--payload-bytes", type=int, default=4)
+    ap.add_argument("--dist", default="morton30", choices=["morton30", "random", "sorted", "equal"])
+    args = ap.parse_args()
+    ctx = mrs.Context(0)
+    n = 1 << args.log2n
+    algo = mrs.ALGO_ONESWEEP if args.algo == "onesweep" else mrs.ALGO_THREE_KERNEL
+    plan = mrs.SortPlan(ctx, n, key_words=args.key_words, payload_bytes=args.payload_bytes,
+                        digit_bits=args.digit_bits, algo=algo, tile_items=args.tile_items)
+    plan.set_timing(True)
+    kw, pw = args.key_words, args.payload_bytes // 4
+    kb = torch.empty(n * kw, dtype=torch.int32, device=ctx.device)
+    vb = torch.empty(max(1, n * pw), dtype=torch.int32, device=ctx.device)
+    rows = []
+    for it in range(args.iters):
+        if args.dist == "morton30":
+            xyz = ctx.generate_points(7 + it, n)
+            mn, mx = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+            keys, idx = ctx.morton_encode30(xyz, mn, mx)
+            del xyz
+            if kw == 2:
+                keys = torch.stack([keys, ctx.generate_u32(3, it, n)], dim=1).reshape(-1).contiguous()
+        else:
+            keys = ctx.generate_u32(7 + it, 1, n * kw)
+            if args.dist == "sorted":
+                keys = torch.sort(keys)[0]
+            elif args.dist == "equal":
+                keys.fill_(12345)
+            idx = torch.arange(n, dtype=torch.int32, device=ctx.device)
+        vals = idx if pw == 1 else (ctx.generate_u32(5, it, n * pw) if pw else None)
+        plan.sort_pairs(keys, vals, kb, vb if pw else None)
+        tm = plan.timings()
+        plan.check()
+        rows.append(tm)
+    last = rows[-1]
+    total = sum(ms for _, ms in last)
+    print(json.dumps({"n": n, "tile_items": plan.info.tile_items, "threads": plan.info.threads,
+                      "launches": [(lab, round(ms, 4)) for lab, ms in last], "total_ms": round(total, 4),
+                      "gkeys_per_s": round(n / total / 1e6, 3)}))
+
+
+if __name__ == "__main__":
+    main()

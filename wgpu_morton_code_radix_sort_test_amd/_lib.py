@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "csrc", "libmrs.so")
+# MRS_LIBRARY_PATH points at another build of the same library (diagnostic builds)
+_LIB_PATH = os.environ.get("MRS_LIBRARY_PATH") or os.path.join(_HERE, "csrc", "libmrs.so")
 
 MRS_OK = 0
 MRS_ERR_INVALID_ARGUMENT = -1

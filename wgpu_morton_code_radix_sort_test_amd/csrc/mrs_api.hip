@@ -169,6 +169,12 @@ __global__ __launch_bounds__(256) void bucket_histogram_kernel(const KeyT* __res
 
 using namespace mrs;
 
+#ifdef MRS_STAMPS
+// diagnostic builds only: device buffer that pass 1 of the next sorts writes its phase clocks to
+static unsigned long long* g_debug_stamps = nullptr;
+extern "C" void mrs_debug_set_stamps(unsigned long long* dev) { g_debug_stamps = dev; }
+#endif
+
 extern "C" const char* mrs_last_error_string(void) { return g_last_error.c_str(); }
 
 extern "C" int mrs_version(void) { return (MRS_VERSION_MAJOR << 16) | MRS_VERSION_MINOR; }
@@ -252,17 +258,22 @@ extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_pla
         p->hist = static_cast<uint32_t*>(p->temp);
         p->scan_partials = reinterpret_cast<uint32_t*>(static_cast<char*>(p->temp) + hist_bytes);
     } else {
-        const size_t status_bytes = align_up(p->histogram_len * sizeof(unsigned long long), 256);
-        bytes = kControlBytes + status_bytes + 256;
+        // 32-bit status words carry counts below 2^30
+        p->status_word_bytes = d->n < (1ull << 30) ? 4 : 8;
+        const size_t status_bytes =
+            align_up(p->histogram_len * p->status_word_bytes * static_cast<size_t>(p->num_passes), 256);
+        bytes = 256 + kControlBytes + status_bytes;
         hipError_t e = hipMalloc(&p->temp, bytes);
         if (e != hipSuccess) {
             delete p;
             return fail(MRS_ERR_OUT_OF_MEMORY, "mrs_plan_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         }
-        p->control = static_cast<OnesweepControl*>(p->temp);
-        p->status = reinterpret_cast<unsigned long long*>(static_cast<char*>(p->temp) + kControlBytes);
-        p->error_flag = reinterpret_cast<uint32_t*>(static_cast<char*>(p->temp) + kControlBytes + status_bytes);
-        p->zero_bytes = kControlBytes + status_bytes;
+        // [error flag, 256 B][control block][status words]; everything after the flag is
+        // cleared by one memset at the start of every sort call
+        p->error_flag = static_cast<uint32_t*>(p->temp);
+        p->zero_begin = static_cast<char*>(p->temp) + 256;
+        p->control = reinterpret_cast<OnesweepControl*>(p->zero_begin);
+        p->status = p->zero_begin + kControlBytes;
         e = hipMemset(p->temp, 0, bytes);
         if (e != hipSuccess) {
             (void)hipFree(p->temp);
@@ -352,8 +363,9 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
     plan->num_marks = 0;
     if (int rc = mark(plan, "start", s)) return rc;
     if (plan->desc.algo == MRS_ALGO_ONESWEEP) {
-        const size_t zero = kControlBytes + align_up(static_cast<size_t>(num_tiles) * plan->radix * 8, 256);
-        MRS_HIP_TRY(hipMemsetAsync(plan->temp, 0, zero, s));
+        const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
+        const size_t zero = kControlBytes + align_up(region * plan->num_passes, 256);
+        MRS_HIP_TRY(hipMemsetAsync(plan->zero_begin, 0, zero, s));
         if (int rc = mark(plan, "memset", s)) return rc;
         GlobalHistArgs h{};
         h.keys = keys_a;
@@ -395,10 +407,13 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
             if (int rc = mark(plan, "scatter", s)) return rc;
         } else {
             a.digit_base = plan->control->ghist + static_cast<size_t>(pass) * plan->radix;
-            a.status = plan->status;
+            a.status = plan->status + static_cast<size_t>(pass) * num_tiles * plan->radix * plan->status_word_bytes;
+            a.wide_status = plan->status_word_bytes == 8;
             a.tile_counter = &plan->control->tile_counter[pass];
             a.error_flag = plan->error_flag;
-            a.tag = pass + 1;
+#ifdef MRS_STAMPS
+            a.stamps = pass == 1 ? g_debug_stamps : nullptr;
+#endif
             if (int rc = launch_pass(plan, kModeOnesweep, a, s)) return rc;
             if (int rc = mark(plan, "onesweep_pass", s)) return rc;
         }
@@ -545,8 +560,9 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
     if (int rc = check_pair_buffers(plan, keys_in, vals_in, keys_out, vals_out, "mrs_partition")) return rc;
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
-    const size_t zero = kControlBytes + align_up(static_cast<size_t>(num_tiles) * plan->radix * 8, 256);
-    MRS_HIP_TRY(hipMemsetAsync(plan->temp, 0, zero, s));
+    const size_t zero =
+        kControlBytes + align_up(static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes, 256);
+    MRS_HIP_TRY(hipMemsetAsync(plan->zero_begin, 0, zero, s));
     GlobalHistArgs h{};
     h.keys = keys_in;
     h.n = n32;
@@ -575,8 +591,8 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
     a.digit_map = map_dev;
     a.digit_base = plan->control->ghist;
     a.status = plan->status;
+    a.wide_status = plan->status_word_bytes == 8;
     a.tile_counter = &plan->control->tile_counter[0];
     a.error_flag = plan->error_flag;
-    a.tag = 1;
     return launch_pass(plan, kModeOnesweep, a, s);
 }

@@ -52,10 +52,13 @@ struct PassArgs {
     const uint32_t* scanned;
     // onesweep
     const uint32_t* digit_base;  // exclusive scan of the global digit histogram of this pass
-    unsigned long long* status;  // [num_tiles][radix] tile status words
+    void* status;                // [num_tiles][radix] tile status words of this pass, zeroed
+    uint32_t wide_status;        // status words are 64-bit (inputs of 2^30 elements and more)
     uint32_t* tile_counter;      // ticket dispenser of this pass
     uint32_t* error_flag;
-    uint32_t tag;                // pass tag stored in the status words (never 0)
+#ifdef MRS_STAMPS
+    unsigned long long* stamps;  // diagnostic builds only: [num_tiles][8] phase clocks
+#endif
 };
 
 // Control block at the start of a onesweep plan's temporary memory; zeroed by
@@ -94,8 +97,9 @@ struct mrs_plan {
     uint64_t scan_partials_len;
     // onesweep
     mrs::OnesweepControl* control;
-    unsigned long long* status;  // [max_tiles][radix]
-    size_t zero_bytes;           // control + status, cleared per call
+    char* status;                // num_passes regions of [num_tiles][radix] status words
+    uint32_t status_word_bytes;  // 4 below 2^30 elements, else 8
+    char* zero_begin;            // control block + status regions: cleared by one memset per call
     uint32_t* error_flag;        // sticky device word
     // optional per-launch timing (mrs_plan_set_timing): events recorded on the
     // caller's stream around every launch of the last mrs_sort_pairs call

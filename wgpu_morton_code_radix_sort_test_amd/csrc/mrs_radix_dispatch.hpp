@@ -13,15 +13,15 @@ namespace mrs {
 //   256 x 4  -- small tiles (16-byte payloads, small inputs)
 // and the large tiles, only for payloads of at most 4 bytes:
 //   512 x 8, 512 x 16 (u32 keys only)
-template <int MODE, int BITS, typename KeyT, typename ValT>
+template <int MODE, bool MAP, int BITS, typename KeyT, typename ValT>
 int launch_pass_shape(int threads, int kpt, const PassArgs& a, hipStream_t s)
 {
-    if (threads == 256 && kpt == 1) return launch_pass_cfg<MODE, BITS, 256, 1, KeyT, ValT>(a, s);
-    if (threads == 256 && kpt == 4) return launch_pass_cfg<MODE, BITS, 256, 4, KeyT, ValT>(a, s);
+    if (threads == 256 && kpt == 1) return launch_pass_cfg<MODE, MAP, BITS, 256, 1, KeyT, ValT>(a, s);
+    if (threads == 256 && kpt == 4) return launch_pass_cfg<MODE, MAP, BITS, 256, 4, KeyT, ValT>(a, s);
     if constexpr (sizeof(ValT) <= 4) {
-        if (threads == 512 && kpt == 8) return launch_pass_cfg<MODE, BITS, 512, 8, KeyT, ValT>(a, s);
+        if (threads == 512 && kpt == 8) return launch_pass_cfg<MODE, MAP, BITS, 512, 8, KeyT, ValT>(a, s);
         if constexpr (sizeof(KeyT) == 4) {
-            if (threads == 512 && kpt == 16) return launch_pass_cfg<MODE, BITS, 512, 16, KeyT, ValT>(a, s);
+            if (threads == 512 && kpt == 16) return launch_pass_cfg<MODE, MAP, BITS, 512, 16, KeyT, ValT>(a, s);
         }
     }
     return fail(MRS_ERR_UNSUPPORTED, "no kernel for %d threads x %d keys per thread", threads, kpt);
@@ -30,8 +30,15 @@ int launch_pass_shape(int threads, int kpt, const PassArgs& a, hipStream_t s)
 template <int MODE, typename KeyT, typename ValT>
 int launch_pass_bits(int bits, int threads, int kpt, const PassArgs& a, hipStream_t s)
 {
-    if (bits == 4) return launch_pass_shape<MODE, 4, KeyT, ValT>(threads, kpt, a, s);
-    if (bits == 8) return launch_pass_shape<MODE, 8, KeyT, ValT>(threads, kpt, a, s);
+    // the bucket -> part table is only used by the partition pass (onesweep machinery)
+    if constexpr (MODE == kModeOnesweep) {
+        if (a.digit_map) {
+            if (bits == 4) return launch_pass_shape<MODE, true, 4, KeyT, ValT>(threads, kpt, a, s);
+            if (bits == 8) return launch_pass_shape<MODE, true, 8, KeyT, ValT>(threads, kpt, a, s);
+        }
+    }
+    if (bits == 4) return launch_pass_shape<MODE, false, 4, KeyT, ValT>(threads, kpt, a, s);
+    if (bits == 8) return launch_pass_shape<MODE, false, 8, KeyT, ValT>(threads, kpt, a, s);
     return fail(MRS_ERR_UNSUPPORTED, "digit_bits must be 4 or 8");
 }
 
