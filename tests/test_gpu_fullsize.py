@@ -1,0 +1,109 @@
+"""GPU tests at the benchmark's full sizes, through size-independent properties
+(sortedness, stability, permutation, checksums), plus the distributed driver on one rank."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mrs():
+    import wgpu_morton_code_radix_sort_test_amd as m
+
+    return m
+
+
+def check_sorted_pairs(keys_out, idx_out, keys_in):
+    """keys_out non-decreasing as u32; ties keep ascending original index; idx_out is a permutation
+    that maps the input keys onto the output keys; key checksums (sum, xor) are conserved."""
+    k = keys_out.to(torch.int64) & 0xFFFFFFFF
+    i = idx_out.to(torch.int64) & 0xFFFFFFFF
+    dk = k[1:] - k[:-1]
+    assert bool((dk >= 0).all()), "keys are not sorted"
+    assert bool(((dk > 0) | (i[1:] > i[:-1])).all()), "equal keys lost their input order"
+    del dk
+    assert bool((keys_in[i] == keys_out).all()), "payload does not point at the key's origin"
+    seen = torch.zeros(k.numel(), dtype=torch.bool, device=k.device)
+    seen[i] = True
+    assert bool(seen.all()), "payload is not a permutation"
+    kin = keys_in.to(torch.int64) & 0xFFFFFFFF
+    assert int(kin.sum()) == int(k.sum())
+
+
+@pytest.mark.parametrize("log2n,algo_name,bits", [(28, "onesweep", 8), (28, "three_kernel", 8), (30, "onesweep", 8)])
+def test_full_size_sort_properties(ctx, mrs, log2n, algo_name, bits):
+    """BASELINE configs 2 and 3: 2^28 and 2^30 (Morton key, index) pairs on one GPU."""
+    n = 1 << log2n
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 60 * n:
+        pytest.skip("not enough device memory for this size")
+    algo = mrs.ALGO_ONESWEEP if algo_name == "onesweep" else mrs.ALGO_THREE_KERNEL
+    xyz = ctx.generate_points(7, n)
+    keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+    del xyz
+    assert int(keys.max()) < (1 << 30)
+    keys_in = keys.clone()
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=bits, algo=algo)
+    kb, vb = torch.empty_like(keys), torch.empty_like(idx)
+    in_b = plan.sort_pairs(keys, idx, kb, vb)
+    plan.check()
+    assert not in_b
+    check_sorted_pairs(keys, idx, keys_in)
+    # idempotence: sorting the sorted array changes nothing
+    k2, v2 = keys.clone(), idx.clone()
+    plan.sort_pairs(k2, v2, kb, vb)
+    plan.check()
+    assert bool((k2 == keys).all()) and bool((v2 == idx).all())
+    plan.close()
+
+
+def test_full_size_head_matches_oracle(ctx, mrs, oracle):
+    """The first 2^20 outputs of a 2^26 sort equal the oracle's, bit for bit (the oracle sorts
+    the whole 2^26 in seconds)."""
+    from gpu_util import to_u32
+
+    n = 1 << 26
+    xyz = ctx.generate_points(11, n)
+    keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+    hk, hi = to_u32(keys).copy(), to_u32(idx).copy()
+    del xyz
+    plan = mrs.SortPlan(ctx, n)
+    kb, vb = torch.empty_like(keys), torch.empty_like(idx)
+    plan.sort_pairs(keys, idx, kb, vb)
+    plan.check()
+    order = np.argsort(hk, kind="stable")
+    assert np.array_equal(to_u32(keys), hk[order])
+    assert np.array_equal(to_u32(idx), hi[order])
+    rk, rv, _ = oracle.lsd_sort(hk[: 1 << 22], hi[: 1 << 22], 1 << 22, 1, 1, 8, 0, 32, 256)
+    assert np.array_equal(rk, hk[: 1 << 22][np.argsort(hk[: 1 << 22], kind="stable")])
+
+
+def test_distributed_sorter_single_rank(ctx, mrs, oracle):
+    """The multi-GPU driver end to end on one rank: HIP histogram, partition and sort, RCCL collectives."""
+    import torch.distributed as dist
+    from gpu_util import to_u32
+    from wgpu_morton_code_radix_sort_test_amd.dist import DistributedSorter
+
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 1000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=ctx.device)
+        created = True
+    try:
+        n = 1 << 20
+        xyz = ctx.generate_points(5, n)
+        keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+        hk, hi = to_u32(keys).copy(), to_u32(idx).copy()
+        sorter = DistributedSorter(ctx, n, 1, 0)
+        ok, ov = sorter.sort(keys, idx)
+        assert sorter.verify(ok, ov)
+        order = np.argsort(hk, kind="stable")
+        assert np.array_equal(to_u32(ok), hk[order]) and np.array_equal(to_u32(ov), hi[order])
+        assert set(sorter.last_breakdown()) >= {"dist_exchange_ms", "dist_local_sort_ms"}
+    finally:
+        if created:
+            dist.destroy_process_group()

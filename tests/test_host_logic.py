@@ -1,0 +1,127 @@
+"""CPU tests of the host side: scene construction, generators, buffer layouts, the planner
+helpers, and that libmrs.so loads and exports every symbol include/mrs.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+from wgpu_morton_code_radix_sort_test_amd import _lib, scene
+from wgpu_morton_code_radix_sort_test_amd.dist import bucket_to_rank_map
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_numpy_generator_matches_oracle(oracle):
+    for n in (1, 7, 1000):
+        assert np.array_equal(scene.rand_u32(7, 3, n), oracle.gen_u32(7, 3, n))
+        assert np.array_equal(scene.gen_points(7, n).view(np.uint32), oracle.gen_points(7, n).view(np.uint32))
+    assert np.array_equal(scene.rand_u32(5, 0, 10, start=90), oracle.gen_u32(5, 0, 100)[90:])
+
+
+def test_utilities_match_reference_tests(oracle):
+    # src/tests.rs:104-113
+    assert scene.calculate_number_of_workgroups(0, 256) == 0
+    for i in range(1, 256):
+        assert scene.calculate_number_of_workgroups(i, 256) == 1
+    for i in range(257, 512):
+        assert scene.calculate_number_of_workgroups(i, 256) == 2
+    for n in (1, 255, 1024, 1025, 3000, 1 << 16, 1 << 20, (1 << 20) + 1, 1 << 28):
+        assert scene.calculate_num_items_prefix_buffers(n) == oracle.prefix_buffer_sizes(n)
+    assert scene.round_up(3000, 256) == 3072 and scene.round_up(512, 256) == 512
+
+
+def test_uniform_blob_layout():
+    """Offsets of MortonCodeConstants (src/shaders/morton_code.wgsl:19-26)."""
+    positions, indices, gen = scene.create_scene()
+    blob = scene.create_morton_uniforms(gen)
+    assert blob.size == 51248
+    lut = blob[:18432].view(np.uint32)
+    assert lut.size == 4608
+    # u64 -> (lo, hi) flattening, src/main.rs:178-182
+    assert lut[2 * (256 * 4 + 7)] == np.uint32(gen.lut[4, 7] & np.uint64(0xFFFFFFFF))
+    assert lut[2 * (256 * 4 + 7) + 1] == np.uint32(gen.lut[4, 7] >> np.uint64(32))
+    size_lut = blob[18432:51200].view(np.uint32)
+    assert size_lut.size == 8192 and size_lut[2 * 100] == 100 and size_lut[2 * 100 + 1] == 0
+    assert blob[51200:51204].view(np.float32)[0] == gen.morton_index_scale
+    assert np.array_equal(blob[51216:51228].view(np.float32), gen.offset)
+    assert blob[51228:51232].view(np.float32)[0] == gen.size_multiplier
+    assert np.array_equal(blob[51232:51244].view(np.float32), gen.multiplier)
+
+
+def test_scene_matches_reference_shape():
+    positions, indices, gen = scene.create_scene()
+    assert positions.shape == (1000, 3) and indices.shape == (3000, 3)
+    assert positions.min() >= 0.0 and positions.max() < 1.0
+    assert indices.max() < 1000
+    used = positions[indices.reshape(-1)]
+    assert np.array_equal(gen.offset, used.min(axis=0))  # bounds over USED vertices, src/main.rs:148-154
+    verts = scene.pack_vertices(positions)
+    tris = scene.pack_triangles(indices)
+    assert verts.size == 1000 * 48 and tris.size == 3000 * 16
+    rec = verts.view(np.float32).reshape(1000, 12)
+    assert np.array_equal(rec[:, :3], positions)
+    assert np.all(rec[:, 4:7] == np.array([0, 1, 0], dtype=np.float32))  # normal, src/main.rs:134
+    assert np.all(rec[:, 8:10] == np.array([0, 0.5], dtype=np.float32))  # uv, src/main.rs:135
+    assert np.array_equal(tris.view(np.uint32).reshape(3000, 4)[:, :3], indices)
+
+
+def test_standin_lut_encodes_a_morton_order(oracle):
+    """The stand-in tables give codes that order points like a 27-bit Morton code."""
+    positions, indices, gen = scene.create_scene(200, 500, 3)
+    blob = scene.create_morton_uniforms(gen)
+    codes = oracle.morton_encode_lut(blob, scene.pack_vertices(positions), scene.pack_triangles(indices))
+    code64 = codes.view(np.uint64)
+    assert np.all((code64 >> np.uint64(12)) < (1 << 27))
+    assert np.all((code64 & np.uint64(0xFFF)) <= 4095)
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mrs.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_symbols()
+    assert len(names) >= 18
+    assert set(names) == set(_lib.SIGNATURES), "the ctypes table and include/mrs.h disagree"
+    lib = _lib.load_library()  # raises if libmrs.so is missing or a symbol is not exported
+    for name in names:
+        assert getattr(lib, name) is not None
+    assert lib.mrs_version() == (0 << 16) | 1
+    assert lib.mrs_last_error_string() == b""
+
+
+def test_library_reports_errors_without_a_gpu():
+    """Argument validation runs before any HIP call."""
+    lib = _lib.load_library()
+    assert lib.mrs_plan_get_info(None, None) == _lib.MRS_ERR_INVALID_ARGUMENT
+    assert b"null" in lib.mrs_last_error_string()
+    assert lib.mrs_context_create(0, None) == _lib.MRS_ERR_INVALID_ARGUMENT
+    assert lib.mrs_sort_pairs(None, 0, None, None, None, None, None, None) == _lib.MRS_ERR_INVALID_ARGUMENT
+
+
+def test_bucket_to_rank_map():
+    counts = np.zeros(4096, dtype=np.int64)
+    counts[:1024] = 100  # Morton keys below 2^30: only the low quarter of the top-12-bit buckets is used
+    for world in (1, 2, 4, 8):
+        table = bucket_to_rank_map(counts, world)
+        assert table.dtype == np.uint8 and table.size == 4096
+        assert np.all(np.diff(table.astype(np.int64)) >= 0) and table.max() <= world - 1
+        per_rank = np.bincount(table, weights=counts, minlength=world)
+        assert np.all(per_rank == counts.sum() / world)
+    # skewed histogram: the split stays within one bucket of the ideal
+    rng = np.random.default_rng(1)
+    counts = rng.integers(0, 1000, size=4096).astype(np.int64)
+    counts[77] = 200000
+    table = bucket_to_rank_map(counts, 8)
+    per_rank = np.bincount(table, weights=counts, minlength=8)
+    ideal = counts.sum() / 8
+    assert np.all(np.diff(table.astype(np.int64)) >= 0)
+    assert np.abs(per_rank - ideal).max() <= 200000
+    # everything in one bucket: one rank takes it all
+    counts = np.zeros(256, dtype=np.int64)
+    counts[9] = 5
+    table = bucket_to_rank_map(counts, 4)
+    assert np.bincount(table, weights=counts, minlength=4).max() == 5
