@@ -1,0 +1,126 @@
+//! Rust declarations of the C ABI in `include/mrs.h` and a thin safe wrapper.
+//!
+//! SOURCE ONLY: the build image has no rustc/cargo, so this file has not been compiled.
+//! It shows what a maintainer of the reference adds in place of its wgpu plumbing
+//! (`bind_group_layouts.rs`, `shader_modules.rs`, the pipeline and bind-group code of
+//! `src/main.rs:256-576`).  Link with `cargo:rustc-link-lib=dylib=mrs`.
+#![allow(non_camel_case_types)]
+use std::ffi::{c_char, c_int, c_void, CStr};
+
+pub const MRS_OK: c_int = 0;
+pub const ALGO_THREE_KERNEL: i32 = 0;
+pub const ALGO_ONESWEEP: i32 = 1;
+pub const MORTON_UNIFORMS_BYTES: usize = 51248;
+
+#[repr(C)]
+pub struct mrs_context { _private: [u8; 0] }
+#[repr(C)]
+pub struct mrs_plan { _private: [u8; 0] }
+
+/// Replaces the constants of `src/constants.rs` and the sizing of `create_all_buffers`.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct PlanDesc {
+    pub n: u64,
+    pub key_words: i32,
+    pub payload_bytes: i32,
+    pub digit_bits: i32,
+    pub begin_bit: i32,
+    pub end_bit: i32,
+    pub algo: i32,
+    pub tile_items: i32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct PlanInfo {
+    pub num_passes: u32,
+    pub radix: u32,
+    pub tile_items: u32,
+    pub threads: u32,
+    pub max_tiles: u64,
+    pub histogram_len: u64,
+    pub temp_bytes: u64,
+}
+
+extern "C" {
+    pub fn mrs_last_error_string() -> *const c_char;
+    pub fn mrs_version() -> c_int;
+    pub fn mrs_context_create(device_id: c_int, out: *mut *mut mrs_context) -> c_int;
+    pub fn mrs_context_destroy(ctx: *mut mrs_context) -> c_int;
+    pub fn mrs_plan_create(ctx: *mut mrs_context, desc: *const PlanDesc, out: *mut *mut mrs_plan) -> c_int;
+    pub fn mrs_plan_destroy(plan: *mut mrs_plan) -> c_int;
+    pub fn mrs_plan_get_info(plan: *const mrs_plan, info: *mut PlanInfo) -> c_int;
+    pub fn mrs_plan_check(plan: *mut mrs_plan, stream: *mut c_void) -> c_int;
+    pub fn mrs_plan_set_timing(plan: *mut mrs_plan, enable: c_int) -> c_int;
+    pub fn mrs_plan_get_timings(plan: *mut mrs_plan, cap: c_int, ms_out: *mut f32, labels_out: *mut c_char,
+                                count_out: *mut c_int) -> c_int;
+    pub fn mrs_morton_encode_lut(ctx: *mut mrs_context, uniforms_dev: *const c_void, vertices_dev: *const c_void,
+                                 num_vertices: u64, triangles_dev: *const c_void, n: u64, codes_dev: *mut u32,
+                                 stream: *mut c_void) -> c_int;
+    pub fn mrs_morton_encode30(ctx: *mut mrs_context, xyz_dev: *const f32, n: u64, mn: *const f32, mx: *const f32,
+                               keys_dev: *mut u32, idx_dev: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn mrs_sort_pairs(plan: *mut mrs_plan, n: u64, keys_a: *mut c_void, vals_a: *mut c_void,
+                          keys_b: *mut c_void, vals_b: *mut c_void, stream: *mut c_void,
+                          result_in_b: *mut c_int) -> c_int;
+    pub fn mrs_histogram(plan: *mut mrs_plan, n: u64, keys_dev: *const c_void, pass: u32, hist_dev: *mut u32,
+                         stream: *mut c_void) -> c_int;
+    pub fn mrs_scan(plan: *mut mrs_plan, n: u64, hist_dev: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn mrs_scatter(plan: *mut mrs_plan, n: u64, keys_in: *const c_void, vals_in: *const c_void,
+                       keys_out: *mut c_void, vals_out: *mut c_void, scanned_hist_dev: *const u32, pass: u32,
+                       stream: *mut c_void) -> c_int;
+    pub fn mrs_bucket_histogram(ctx: *mut mrs_context, keys_dev: *const c_void, n: u64, key_words: i32,
+                                shift: u32, bits: u32, counts_dev: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn mrs_partition(plan: *mut mrs_plan, n: u64, keys_in: *const c_void, vals_in: *const c_void,
+                         keys_out: *mut c_void, vals_out: *mut c_void, shift: u32, bits: u32,
+                         map_dev: *const u8, num_parts: u32, part_counts_dev: *mut u32,
+                         stream: *mut c_void) -> c_int;
+    pub fn mrs_generate_points(ctx: *mut mrs_context, seed: u64, n: u64, xyz_dev: *mut f32,
+                               stream: *mut c_void) -> c_int;
+    pub fn mrs_generate_u32(ctx: *mut mrs_context, seed: u64, stream_id: u64, n: u64, out_dev: *mut u32,
+                            stream: *mut c_void) -> c_int;
+}
+
+#[derive(Debug)]
+pub struct Error { pub code: i32, pub message: String }
+pub type Result<T> = std::result::Result<T, Error>;
+
+fn check(rc: c_int) -> Result<()> {
+    if rc == MRS_OK { return Ok(()); }
+    let message = unsafe { CStr::from_ptr(mrs_last_error_string()) }.to_string_lossy().into_owned();
+    Err(Error { code: rc, message })
+}
+
+pub struct Context { raw: *mut mrs_context }
+impl Context {
+    pub fn new(device_id: i32) -> Result<Self> {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { mrs_context_create(device_id, &mut raw) })?;
+        Ok(Self { raw })
+    }
+    /// "Morton Coding" (src/main.rs:581-592); all pointers are device pointers.
+    pub fn morton_encode_lut(&self, uniforms: *const c_void, vertices: *const c_void, num_vertices: u64,
+                             triangles: *const c_void, n: u64, codes: *mut u32, stream: *mut c_void) -> Result<()> {
+        check(unsafe { mrs_morton_encode_lut(self.raw, uniforms, vertices, num_vertices, triangles, n, codes, stream) })
+    }
+}
+impl Drop for Context { fn drop(&mut self) { unsafe { mrs_context_destroy(self.raw); } } }
+
+pub struct Plan { raw: *mut mrs_plan }
+impl Plan {
+    pub fn new(ctx: &Context, desc: PlanDesc) -> Result<Self> {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { mrs_plan_create(ctx.raw, &desc, &mut raw) })?;
+        Ok(Self { raw })
+    }
+    /// The NUM_PASSES loop (src/main.rs:594-665).  Returns true when the result is in the
+    /// second buffer pair (odd pass count, src/main.rs:819-823).
+    pub fn sort_pairs(&self, n: u64, keys_a: *mut c_void, vals_a: *mut c_void, keys_b: *mut c_void,
+                      vals_b: *mut c_void, stream: *mut c_void) -> Result<bool> {
+        let mut in_b: c_int = 0;
+        check(unsafe { mrs_sort_pairs(self.raw, n, keys_a, vals_a, keys_b, vals_b, stream, &mut in_b) })?;
+        Ok(in_b != 0)
+    }
+    pub fn check(&self, stream: *mut c_void) -> Result<()> { check(unsafe { mrs_plan_check(self.raw, stream) }) }
+}
+impl Drop for Plan { fn drop(&mut self) { unsafe { mrs_plan_destroy(self.raw); } } }

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output under gpurun_out/ into the tracked files under profiles/.
+
+  profiles/<tag>_kernel_stats.csv  : --kernel-trace --stats summary, library kernels only
+  profiles/traffic.json            : HBM bytes per launch of the dominant kernel from the PMC passes
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half the bytes of a streaming
+read; the factor is CALIBRATED here on kernels of known byte counts in the same run
+(morton_encode30: 12 B read per point; global_histogram: 4 B per key) and applied to the pass.
+WRITE_SIZE is exact for streaming stores (checked on morton_encode30: 8 B per point).
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counter_means(pattern, counter):
+    out = collections.defaultdict(list)
+    for path in glob.glob(pattern):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in out.items()}
+
+
+def pick(d, needle):
+    for k, v in d.items():
+        if needle in k:
+            return v
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", default="r01")
+    ap.add_argument("--stats-dir", default="gpurun_out/prof_r01b")
+    ap.add_argument("--fetch-dir", default="gpurun_out/pmc_fetch")
+    ap.add_argument("--write-dir", default="gpurun_out/pmc_write")
+    ap.add_argument("--log2n", type=int, default=28)
+    args = ap.parse_args()
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    n = 1 << args.log2n
+
+    for path in glob.glob(os.path.join(ROOT, args.stats_dir, "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.reader(open(path)))
+        keep = [rows[0]] + [r for r in rows[1:] if "mrs::" in r[0] or "rocclr" in r[0]]
+        with open(os.path.join(ROOT, "profiles", f"{args.tag}_kernel_stats.csv"), "w", newline="") as f:
+            csv.writer(f).writerows(keep)
+
+    fetch = counter_means(os.path.join(ROOT, args.fetch_dir, "**", "*counter_collection.csv"), "FETCH_SIZE")
+    write = counter_means(os.path.join(ROOT, args.write_dir, "**", "*counter_collection.csv"), "WRITE_SIZE")
+    if fetch and write:
+        enc_f, hist_f = pick(fetch, "morton_encode30"), pick(fetch, "global_histogram_kernel")
+        enc_w = pick(write, "morton_encode30")
+        cal_enc = 12.0 * n / (enc_f * 1024.0)
+        cal_hist = 4.0 * n / (hist_f * 1024.0)
+        cal_w = 8.0 * n / (enc_w * 1024.0)
+        factor = 0.5 * (cal_enc + cal_hist)
+        pass_f, pass_w = pick(fetch, "digit_pass_kernel<1"), pick(write, "digit_pass_kernel<1")
+        read_b = pass_f * 1024.0 * factor
+        write_b = pass_w * 1024.0 * cal_w
+        out = {
+            "kernel": "digit_pass_kernel<onesweep>",
+            "n": n,
+            "bytes_per_launch": read_b + write_b,
+            "read_bytes_per_launch": read_b,
+            "write_bytes_per_launch": write_b,
+            "algorithmic_bytes_per_launch": 16.0 * n,
+            "FETCH_SIZE_KiB": pass_f,
+            "WRITE_SIZE_KiB": pass_w,
+            "fetch_calibration": {"morton_encode30 (12 B/point)": cal_enc, "global_histogram (4 B/key)": cal_hist,
+                                  "applied": factor},
+            "write_calibration": {"morton_encode30 (8 B/point)": cal_w},
+            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs of tools/sort_once.py",
+        }
+        with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
+            json.dump(out, f, indent=1)
+        print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
