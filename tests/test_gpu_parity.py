@@ -154,14 +154,27 @@ def test_sort_distributions(ctx, oracle, mrs, algo_name, dist):
         assert np.array_equal(ko, sk) and np.array_equal(vo, sv)
 
 
-@pytest.mark.parametrize("tile", [256, 1024, 4096, 8192])
+@pytest.mark.parametrize("tile", [256, 1024, 4096, 8192, 16384, 32768])
 @pytest.mark.parametrize("algo_name", ["three_kernel", "onesweep"])
 def test_sort_tile_shapes(ctx, oracle, mrs, tile, algo_name):
     algo = mrs.ALGO_ONESWEEP if algo_name == "onesweep" else mrs.ALGO_THREE_KERNEL
-    n = 50001
+    n = 50001 if tile <= 8192 else 12 * tile + 77
     keys = make_keys(oracle, n, 1, "morton30")
     vals = make_vals(oracle, n, 1)
     ko, vo, _ = gpu_sort(ctx, mrs, keys, vals, n, 1, 1, 8, 0, 32, algo, tile_items=tile)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+@pytest.mark.parametrize("tile", [256, 1024])
+@pytest.mark.parametrize("dist", ["random", "all_equal"])
+def test_onesweep_long_chains(ctx, oracle, mrs, tile, dist):
+    """Thousands of tiles: the look-back walks over many windows and, with all keys equal,
+    every tile's count of one digit goes through the chain."""
+    n = (1 << 20) + 123
+    keys = make_keys(oracle, n, 1, dist)
+    vals = make_vals(oracle, n, 1)
+    ko, vo, _ = gpu_sort(ctx, mrs, keys, vals, n, 1, 1, 8, 0, 32, mrs.ALGO_ONESWEEP, tile_items=tile)
     rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
     assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
 

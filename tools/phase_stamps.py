@@ -18,7 +18,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wgpu_morton_code_radix_sort_test_amd as mrs  # noqa: E402
 
-NAMES = ["ticket", "load", "hist+publish", "rank", "bases+stage", "lookback", "write_out"]
+NAMES = ["-", "key wait", "rank", "hist+bases", "stage+issue", "lookback", "write_out"]
 
 
 def main():
@@ -52,6 +52,17 @@ def main():
         col = d[:, k]
         print(f"{name:12s} mean {col.mean():8.2f}  p10 {np.percentile(col, 10):8.2f}  p50 {np.percentile(col, 50):8.2f}  "
               f"p90 {np.percentile(col, 90):8.2f}  max {col.max():8.2f}")
+    # finer stamps: 11 first look-back words reduced, 12 first look-back barrier passed,
+    # 13 key stores issued, 14 payload staged in LDS
+    fine = raw[:, 11:15].astype(np.float64) / 100.0
+    have = raw[:, 11] != 0
+    if have.any():
+        for name, col in (("  lb words in", fine[:, 0] - st[:, 5]), ("  lb barrier", fine[:, 1] - fine[:, 0]),
+                          ("  lb combine", st[:, 6] - fine[:, 1]), ("  key stores", fine[:, 2] - st[:, 6]),
+                          ("  val staged", fine[:, 3] - fine[:, 2]), ("  val stores", st[:, 7] - fine[:, 3])):
+            col = col[have]
+            print(f"{name:14s} mean {col.mean():8.2f}  p10 {np.percentile(col, 10):8.2f}  p50 {np.percentile(col, 50):8.2f}  "
+                  f"p90 {np.percentile(col, 90):8.2f}")
     life = st[:, 7] - st[:, 0]
     print(f"{'tile life':12s} mean {life.mean():8.2f}  p50 {np.percentile(life, 50):8.2f}  p90 {np.percentile(life, 90):8.2f}")
     for k, name in ((8, "lookback round trips"), (9, "tiles walked"), (10, "empty rounds")):

@@ -4,6 +4,7 @@
 // (src/main.rs:594-665): for every digit it enqueues the histogram, prefix-sum
 // and scatter stages on one stream with ping-pong buffers
 // (src/main.rs:515-576), with no host synchronisation in between.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -37,28 +38,40 @@ int launch_block_histogram_u64(int bits, uint32_t n, const void* keys, uint32_t 
 int launch_global_histogram_u32(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
 int launch_global_histogram_u64(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
 
-bool config_supported(int key_words, int payload_bytes, int digit_bits, int tile_items, int algo, KernelConfig* cfg)
+bool config_supported(unsigned long long n, int key_words, int payload_bytes, int digit_bits, int tile_items, int algo,
+                      KernelConfig* cfg)
 {
     (void)algo;
     if (key_words != 1 && key_words != 2) return false;
     if (payload_bytes != 0 && payload_bytes != 4 && payload_bytes != 16) return false;
     if (digit_bits != 4 && digit_bits != 8) return false;
+    const bool small_pairs = key_words == 1 && payload_bytes <= 4;  // the shapes of 8192 elements and more
     KernelConfig c;
     switch (tile_items) {
         case 0:
+            // Larger tiles scatter longer runs per digit and walk fewer tile status words, as
+            // long as the input still yields several tiles per compute unit.
             if (payload_bytes == 16) c = {256, 4};
             else if (key_words == 2) c = {512, 8};
+            else if (n >= (1ull << 25)) c = {1024, 32};
+            else if (n >= (1ull << 24)) c = {1024, 16};
             else c = {512, 16};
             break;
         case 256: c = {256, 1}; break;
         case 1024: c = {256, 4}; break;
         case 4096: c = {512, 8}; break;
         case 8192: c = {512, 16}; break;
+        case 16384: c = {1024, 16}; break;
+        case 32768: c = {1024, 32}; break;
         default: return false;
     }
-    const bool large = c.threads == 512;
-    if (large && payload_bytes == 16) return false;
-    if (c.threads == 512 && c.kpt == 16 && key_words == 2) return false;
+    // tuning aid: MRS_TILE_SHAPE=threads,kpt overrides the shape of 32-bit-key plans with small payloads
+    if (const char* e = std::getenv("MRS_TILE_SHAPE")) {
+        int t = 0, k = 0;
+        if (std::sscanf(e, "%d,%d", &t, &k) == 2 && small_pairs && tile_items == 0) c = {t, k};
+    }
+    if (c.threads * c.kpt >= 4096 && payload_bytes == 16) return false;
+    if (c.threads * c.kpt >= 8192 && !small_pairs) return false;
     if (cfg) *cfg = c;
     return true;
 }
@@ -218,7 +231,7 @@ extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_pla
     if (d->algo != MRS_ALGO_THREE_KERNEL && d->algo != MRS_ALGO_ONESWEEP)
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_create: unknown algo %d", d->algo);
     KernelConfig cfg;
-    if (!config_supported(d->key_words, d->payload_bytes, d->digit_bits, d->tile_items, d->algo, &cfg))
+    if (!config_supported(d->n, d->key_words, d->payload_bytes, d->digit_bits, d->tile_items, d->algo, &cfg))
         return fail(MRS_ERR_UNSUPPORTED,
                     "mrs_plan_create: unsupported shape (key_words %d, payload_bytes %d, digit_bits %d, tile_items %d)",
                     d->key_words, d->payload_bytes, d->digit_bits, d->tile_items);
@@ -258,8 +271,11 @@ extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_pla
         p->hist = static_cast<uint32_t*>(p->temp);
         p->scan_partials = reinterpret_cast<uint32_t*>(static_cast<char*>(p->temp) + hist_bytes);
     } else {
-        // 32-bit status words carry counts below 2^30
-        p->status_word_bytes = d->n < (1ull << 30) ? 4 : 8;
+        // 32-bit status words carry counts below 2^30; the kernels instantiated for them also
+        // address keys and payload with 32-bit byte offsets, so no array may exceed 4 GiB
+        const unsigned long long elem_bytes =
+            std::max<unsigned long long>(4ull * d->key_words, static_cast<unsigned long long>(d->payload_bytes));
+        p->status_word_bytes = (d->n < (1ull << 30) && d->n * elem_bytes <= (1ull << 32)) ? 4 : 8;
         const size_t status_bytes =
             align_up(p->histogram_len * p->status_word_bytes * static_cast<size_t>(p->num_passes), 256);
         bytes = 256 + kControlBytes + status_bytes;
@@ -409,6 +425,8 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
             a.digit_base = plan->control->ghist + static_cast<size_t>(pass) * plan->radix;
             a.status = plan->status + static_cast<size_t>(pass) * num_tiles * plan->radix * plan->status_word_bytes;
             a.wide_status = plan->status_word_bytes == 8;
+            a.num_cus = plan->ctx->num_cus;
+            a.use_ticket = 1;
             a.tile_counter = &plan->control->tile_counter[pass];
             a.error_flag = plan->error_flag;
 #ifdef MRS_STAMPS
@@ -592,6 +610,8 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
     a.digit_base = plan->control->ghist;
     a.status = plan->status;
     a.wide_status = plan->status_word_bytes == 8;
+    a.num_cus = plan->ctx->num_cus;
+    a.use_ticket = 1;
     a.tile_counter = &plan->control->tile_counter[0];
     a.error_flag = plan->error_flag;
     return launch_pass(plan, kModeOnesweep, a, s);

@@ -56,6 +56,9 @@ struct PassArgs {
     uint32_t wide_status;        // status words are 64-bit (inputs of 2^30 elements and more)
     uint32_t* tile_counter;      // ticket dispenser of this pass
     uint32_t* error_flag;
+    uint32_t num_cus;            // host side only: sizes the grid of the persistent kernel
+    uint32_t first_tile;         // one-tile kernel: index of the tile of workgroup 0
+    uint32_t use_ticket;         // one-tile kernel, onesweep: tile ids come from the ticket counter
 #ifdef MRS_STAMPS
     unsigned long long* stamps;  // diagnostic builds only: [num_tiles][8] phase clocks
 #endif

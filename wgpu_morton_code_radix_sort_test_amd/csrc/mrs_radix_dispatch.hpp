@@ -13,15 +13,27 @@ namespace mrs {
 //   256 x 4  -- small tiles (16-byte payloads, small inputs)
 // and the large tiles, only for payloads of at most 4 bytes:
 //   512 x 8, 512 x 16 (u32 keys only)
+template <int MODE, bool MAP, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
+int launch_pass_any(const PassArgs& a, hipStream_t s)
+{
+    return launch_pass_cfg<MODE, MAP, BITS, THREADS, KPT, KeyT, ValT>(a, s);
+}
+
 template <int MODE, bool MAP, int BITS, typename KeyT, typename ValT>
 int launch_pass_shape(int threads, int kpt, const PassArgs& a, hipStream_t s)
 {
-    if (threads == 256 && kpt == 1) return launch_pass_cfg<MODE, MAP, BITS, 256, 1, KeyT, ValT>(a, s);
-    if (threads == 256 && kpt == 4) return launch_pass_cfg<MODE, MAP, BITS, 256, 4, KeyT, ValT>(a, s);
+    if (threads == 256 && kpt == 1) return launch_pass_any<MODE, MAP, BITS, 256, 1, KeyT, ValT>(a, s);
+    if (threads == 256 && kpt == 4) return launch_pass_any<MODE, MAP, BITS, 256, 4, KeyT, ValT>(a, s);
     if constexpr (sizeof(ValT) <= 4) {
-        if (threads == 512 && kpt == 8) return launch_pass_cfg<MODE, MAP, BITS, 512, 8, KeyT, ValT>(a, s);
+        if (threads == 512 && kpt == 8) return launch_pass_any<MODE, MAP, BITS, 512, 8, KeyT, ValT>(a, s);
         if constexpr (sizeof(KeyT) == 4) {
-            if (threads == 512 && kpt == 16) return launch_pass_cfg<MODE, MAP, BITS, 512, 16, KeyT, ValT>(a, s);
+            if (threads == 512 && kpt == 16) return launch_pass_any<MODE, MAP, BITS, 512, 16, KeyT, ValT>(a, s);
+            if (threads == 256 && kpt == 16) return launch_pass_any<MODE, MAP, BITS, 256, 16, KeyT, ValT>(a, s);
+            if (threads == 256 && kpt == 32) return launch_pass_any<MODE, MAP, BITS, 256, 32, KeyT, ValT>(a, s);
+            if (threads == 1024 && kpt == 16) return launch_pass_any<MODE, MAP, BITS, 1024, 16, KeyT, ValT>(a, s);
+            if (threads == 512 && kpt == 32) return launch_pass_any<MODE, MAP, BITS, 512, 32, KeyT, ValT>(a, s);
+            if (threads == 1024 && kpt == 32) return launch_pass_any<MODE, MAP, BITS, 1024, 32, KeyT, ValT>(a, s);
+            if (threads == 1024 && kpt == 8) return launch_pass_any<MODE, MAP, BITS, 1024, 8, KeyT, ValT>(a, s);
         }
     }
     return fail(MRS_ERR_UNSUPPORTED, "no kernel for %d threads x %d keys per thread", threads, kpt);

@@ -62,6 +62,15 @@ __device__ __forceinline__ void keep_alive(const T& x)
     for (unsigned i = 0; i < (sizeof(T) + 3) / 4; ++i) asm volatile("" ::"v"(w[i]));
 }
 
+// Makes the compiler forget how a value was computed (no instruction is emitted).
+__device__ __forceinline__ void launder(uint32_t& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void launder(unsigned long long& x)
+{
+    uint32_t lo = static_cast<uint32_t>(x), hi = static_cast<uint32_t>(x >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    x = (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 // ticks of the 100 MHz constant clock a look-back may wait before giving up
 constexpr unsigned long long kSpinTimeoutTicks = 400000000ull;  // 4 s
 
@@ -81,18 +90,20 @@ __device__ __forceinline__ uint32_t lanes_below(uint32_t lo, uint32_t hi)
 }
 
 // Mask (as two halves) of the lanes of this wave, among those in `valid`, that hold
-// the same digit as the caller.  Per digit bit: one ballot, then "lanes whose bit
-// equals mine" = ~(ballot ^ x) with x = all-ones when my bit is set.
+// the same digit as the caller.  Per digit bit: x = all-ones where my bit is set, one
+// compare yields the ballot of x, and "lanes whose bit equals mine" = ~(ballot ^ x) is
+// folded into the running mask by one three-input bit operation per half
+// (truth table A & ~(B ^ C) = 0xF0 & ~(0xCC ^ 0xAA) = 0x90): four instructions per bit.
 template <int BITS>
 __device__ __forceinline__ void match_digit(uint32_t d, unsigned long long valid, uint32_t* out_lo, uint32_t* out_hi)
 {
     uint32_t lo = static_cast<uint32_t>(valid), hi = static_cast<uint32_t>(valid >> 32);
 #pragma unroll
     for (int b = 0; b < BITS; ++b) {
-        const uint32_t x = 0u - ((d >> b) & 1u);
-        const unsigned long long bal = __ballot(x != 0u);
-        lo &= ~(static_cast<uint32_t>(bal) ^ x);
-        hi &= ~(static_cast<uint32_t>(bal >> 32) ^ x);
+        const uint32_t x = static_cast<uint32_t>(__builtin_amdgcn_sbfe(d, b, 1));
+        const unsigned long long bal = __builtin_amdgcn_uicmp(x, 0u, 33 /* != */);
+        lo = __builtin_amdgcn_bitop3_b32(lo, static_cast<uint32_t>(bal), x, 0x90);
+        hi = __builtin_amdgcn_bitop3_b32(hi, static_cast<uint32_t>(bal >> 32), x, 0x90);
     }
     *out_lo = lo;
     *out_hi = hi;
@@ -111,67 +122,47 @@ __device__ __forceinline__ void status_store(StatusT* p, StatusT v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Decoupled look-back for one digit: sum of the digit counts of all tiles before
-// `tile`.  Walks back over the predecessors' status words, adding aggregates until
-// an inclusive prefix is found.  J predecessors are fetched per round trip: a
-// dependent read costs microseconds on a busy chip, and the nearest inclusive
-// prefix is as many tiles back as enter look-back during one such read.
-template <int RADIX, typename StatusT>
-__device__ __forceinline__ uint32_t look_back(const PassArgs& a, uint32_t tile, uint32_t digit, bool* failed)
+// Decoupled look-back, one window: the status words of one digit of the J tiles
+// first, first-1, ... are requested.  Tile 0 always publishes an inclusive prefix, so a
+// walk ends at it: slots that would fall below tile 0 re-read tile 0 and are never used.
+template <int RADIX, typename StatusT, int J>
+__device__ __forceinline__ void window_issue(const StatusT* status, int first, uint32_t digit, StatusT (&v)[J])
 {
-    using SB = StatusBits<StatusT>;
-    constexpr int J = SB::kWidth;
-    const StatusT* status = static_cast<const StatusT*>(a.status);
-    uint32_t excl = 0;
-    long long t = static_cast<long long>(tile) - 1;  // nearest predecessor not yet accounted for
-    unsigned long long t0 = 0;
-    uint32_t spins = 0;
-    while (true) {
-        StatusT v[J];
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const long long tj = t - j;
-            // tile 0 always publishes an inclusive prefix, so the walk ends before it
-            // would need a tile below 0
-            v[j] = tj >= 0 ? status_load(status + static_cast<size_t>(tj) * RADIX + digit) : static_cast<StatusT>(0);
-        }
-        bool open = true, found = false;
-        int consumed = 0;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            if (open) {
-                if (v[j] >> SB::kValueBits) {
-                    excl += static_cast<uint32_t>(v[j] & SB::kValueMask);
-                    ++consumed;
-                    if (v[j] & SB::kInclusive) { found = true; open = false; }
-                } else {
-                    open = false;  // not published yet: everything further back waits
-                }
-            }
-        }
-#ifdef MRS_STAMPS
-        if (a.stamps && digit == 0) {
-            a.stamps[static_cast<size_t>(tile) * 16 + 8] += 1;               // round trips
-            a.stamps[static_cast<size_t>(tile) * 16 + 9] += consumed;        // tiles walked
-            a.stamps[static_cast<size_t>(tile) * 16 + 10] += consumed == 0;  // rounds that found nothing
-        }
-#endif
-        if (found) return excl;
-        t -= consumed;
-        if (consumed == 0) {
-            ++spins;
-            if ((spins & 63u) == 0u) {
-                const unsigned long long now = wall_clock64();
-                if (t0 == 0) t0 = now;
-                if (now - t0 > kSpinTimeoutTicks ||
-                    __hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    *failed = true;
-                    return excl;
-                }
-            }
-            __builtin_amdgcn_s_sleep(1);
+    for (int j = 0; j < J; ++j) {
+        const int tj = max(first - j, 0);
+        if constexpr (sizeof(StatusT) == 4) {
+            // at most 2^22 tiles of 256 words: the byte offset fits 32 bits
+            const uint32_t off = (static_cast<uint32_t>(tj) * RADIX + digit) * 4u;
+            v[j] = status_load(reinterpret_cast<const StatusT*>(reinterpret_cast<const char*>(status) + off));
+        } else {
+            v[j] = status_load(status + static_cast<size_t>(tj) * RADIX + digit);
         }
     }
+}
+
+// Sum of the counts of the leading published words of a window, up to and including the
+// first inclusive prefix; *info = words consumed | (inclusive prefix found) << 16.
+template <typename StatusT, int J>
+__device__ __forceinline__ uint32_t window_reduce(const StatusT (&v)[J], uint32_t* info)
+{
+    using SB = StatusBits<StatusT>;
+    uint32_t sum = 0, consumed = 0;
+    bool open = true, found = false;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if (open) {
+            if (v[j] >> SB::kValueBits) {
+                sum += static_cast<uint32_t>(v[j] & SB::kValueMask);
+                ++consumed;
+                if (v[j] & SB::kInclusive) { found = true; open = false; }
+            } else {
+                open = false;  // not published yet: everything further back waits
+            }
+        }
+    }
+    *info = consumed | (found ? 1u << 16 : 0u);
+    return sum;
 }
 
 // Diagnostic builds (-DMRS_STAMPS) record the 100 MHz clock at phase boundaries of
@@ -185,6 +176,51 @@ __device__ __forceinline__ uint32_t look_back(const PassArgs& a, uint32_t tile, 
 #define MRS_STAMP(k) do { } while (0)
 #endif
 
+// base[index] = v.  With OFF32 the byte offset is known to fit 32 bits, which lets the
+// store take a scalar base and a 32-bit register offset instead of a 64-bit address.
+template <bool OFF32, typename T>
+__device__ __forceinline__ void store_element(T* base, uint32_t index, const T& v)
+{
+    if constexpr (OFF32)
+        *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + index * static_cast<uint32_t>(sizeof(T))) = v;
+    else
+        base[index] = v;
+}
+
+// Tile-local positions are below 2^16 (no tile shape exceeds 65536 elements), so two
+// share a register.
+template <int N>
+struct PackedPos {
+    uint32_t w[(N + 1) / 2];
+    __device__ __forceinline__ uint32_t get(int i) const { return (i & 1) ? (w[i / 2] >> 16) : (w[i / 2] & 0xFFFFu); }
+    // first write of element i; the elements are written in ascending order
+    __device__ __forceinline__ void set_fresh(int i, uint32_t v)
+    {
+        if (i & 1) w[i / 2] |= v << 16;
+        else w[i / 2] = v;
+    }
+    __device__ __forceinline__ void set_pair(int j, uint32_t lo, uint32_t hi) { w[j] = lo | (hi << 16); }
+    // overwrite of element i, the other half kept
+    __device__ __forceinline__ void set(int i, uint32_t v)
+    {
+        if (i & 1) w[i / 2] = (w[i / 2] & 0xFFFFu) | (v << 16);
+        else w[i / 2] = (w[i / 2] & 0xFFFF0000u) | v;
+    }
+};
+
+// Digits (at most 8 bits) of N elements, four to a register.
+template <int N>
+struct PackedDigits {
+    uint32_t w[(N + 3) / 4];
+    __device__ __forceinline__ uint32_t get(int i) const { return (w[i / 4] >> (8 * (i & 3))) & 0xFFu; }
+    // first write of element i; the elements are written in ascending order
+    __device__ __forceinline__ void set_fresh(int i, uint32_t d)
+    {
+        if (i & 3) w[i / 4] |= d << (8 * (i & 3));
+        else w[i / 4] = d;
+    }
+};
+
 template <int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
 struct PassShared {
     static constexpr int RADIX = 1 << BITS;
@@ -196,8 +232,16 @@ struct PassShared {
     static constexpr int SCAN_WAVES = (RADIX + 63) / 64;
 
     __attribute__((aligned(16))) unsigned char stage[TILE * STAGE_ELEM];
+    // Look-back: GROUPS threads share the walk of one digit, each fetching LB_WIDTH
+    // predecessors per round trip, so that one round trip usually reaches an inclusive
+    // prefix (a dependent device-scope read costs microseconds on a busy chip).
+    static constexpr int GROUPS = THREADS / RADIX >= 4 ? 4 : (THREADS / RADIX >= 2 ? 2 : 1);
+
     uint32_t wave_hist[WAVES][RADIX];  // per-wave digit counts, later per-wave bases
     uint32_t gbase[RADIX];             // global position of slot 0 of each digit, minus its tile offset
+    uint32_t lb_sum[GROUPS][RADIX];    // look-back: sum over the group's window
+    uint32_t lb_info[GROUPS][RADIX];   // look-back: words consumed | found << 16
+    int lb_next[RADIX];                // look-back: nearest predecessor not yet accounted for
     uint32_t wsum[SCAN_WAVES];
     uint32_t tile;
     uint32_t abort;
@@ -216,6 +260,10 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     constexpr int TILE = S::TILE;
     constexpr bool HAS_VAL = S::HAS_VAL;
     constexpr int SCAN_WAVES = S::SCAN_WAVES;
+    static_assert(TILE <= 65536 && BITS <= 8, "positions are packed in 16 bits, digits in 8");
+    // The host picks 32-bit status words only when every key and payload array is at most
+    // 4 GiB, so byte offsets into them fit 32 bits there.
+    constexpr bool OFF32 = MODE == kModeOnesweep && sizeof(StatusT) == 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -241,10 +289,10 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     // wave_hist[wave][d] carries the running count; the lowest lane of each digit
     // group advances it.  LDS operations of one wave execute in order, so the read
     // of item i+1 sees the update of item i.
-    uint32_t pos[KPT];
+    PackedPos<KPT> pos;
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-        if (kAblate & 2) { pos[i] = 0; continue; }
+        if (kAblate & 2) { pos.set_fresh(i, 0); continue; }
         const uint32_t d = key_digit<MAP>(key[i], a.shift, a.mask, a.digit_map);
         const unsigned long long valid = FULL ? ~0ull : __ballot(my_first + i * 64 < tile_valid);
         uint32_t mlo, mhi;
@@ -253,9 +301,13 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
         const uint32_t prev = sh.wave_hist[wave][d];
         const bool mine = FULL || (my_first + i * 64 < tile_valid);
         if (mine && below == 0) sh.wave_hist[wave][d] = prev + __popc(mlo) + __popc(mhi);
-        pos[i] = prev + below;
+        pos.set_fresh(i, prev + below);
         __builtin_amdgcn_wave_barrier();
     }
+    // The digits and counter addresses of the ranking are cheap to recompute and costly to
+    // keep: hide the keys' provenance so that the staging below does not keep them alive.
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) launder(key[i]);
     __syncthreads();
     MRS_STAMP(3);
 
@@ -295,16 +347,39 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     __syncthreads();
     MRS_STAMP(4);
 
+    // ---- look-back, first round trip ------------------------------------------------------
+    // Requested by every wave before any wave asks for the payload: a status read that
+    // queues behind the payload loads of the whole workgroup comes back microseconds
+    // later.  The staging of the keys below covers part of the round trip.
+    constexpr int GROUPS = S::GROUPS;
+    // tiles of 32 keys per thread are half as many: half the window reaches as far back in time
+    constexpr int J = KPT >= 32 ? SB::kWidth / 2 : SB::kWidth;
+    const int lb_group = tid / RADIX;
+    const uint32_t lb_digit = tid % RADIX;
+    const StatusT* const status = static_cast<const StatusT*>(a.status);
+    // digit d's first output position in the whole array (needed at the end of the look-back)
+    uint32_t digit_base = 0;
+    if (MODE == kModeOnesweep && tid < RADIX) digit_base = a.digit_base[tid];
+    const bool walker = MODE == kModeOnesweep && !(kAblate & 1) && tile != 0 && lb_group < GROUPS;
+    StatusT lbv[J];
+    if (walker) window_issue<RADIX, StatusT, J>(status, static_cast<int>(tile) - 1 - lb_group * J, lb_digit, lbv);
+
     // ---- local sort of the keys through LDS ---------------------------------------
     KeyT* stage_keys = reinterpret_cast<KeyT*>(sh.stage);
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        const uint32_t d = key_digit<MAP>(key[i], a.shift, a.mask, a.digit_map);
-        pos[i] += sh.wave_hist[wave][d];
-        if (kAblate & 2) pos[i] = my_first + i * 64;
-        if (FULL || my_first + i * 64 < tile_valid) stage_keys[pos[i]] = key[i];
+    for (int i = 0; i < KPT; i += 2) {
+        uint32_t p[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2 && i + h < KPT; ++h) {
+            const uint32_t d = key_digit<MAP>(key[i + h], a.shift, a.mask, a.digit_map);
+            p[h] = pos.get(i + h) + sh.wave_hist[wave][d];
+            if (kAblate & 2) p[h] = my_first + (i + h) * 64;
+            if (FULL || my_first + (i + h) * 64 < tile_valid) stage_keys[p[h]] = key[i + h];
+        }
+        pos.set_pair(i / 2, p[0], p[1]);
+        if ((i & 7) == 6) __builtin_amdgcn_sched_barrier(0);  // bounds the registers in flight
     }
-    // The payload is fetched now: its latency hides behind the look-back below, and its
+    // The payload is fetched now: its latency hides behind the look-back, and its
     // registers take over from the keys, which live in LDS from here on.
     ValT val[KPT];
     if constexpr (HAS_VAL) {
@@ -318,65 +393,131 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     MRS_STAMP(5);
 
     // ---- global base of every digit of this tile ------------------------------------
-    if (tid < RADIX) {
-        uint32_t base;
-        if (MODE == kModeScatter) {
-            base = a.scanned[static_cast<size_t>(tid) * a.num_tiles + tile];
-        } else {
-            uint32_t excl = 0;
-            if (tile != 0) {
-                bool failed = false;
-                if (!(kAblate & 1)) excl = look_back<RADIX, StatusT>(a, tile, tid, &failed);
-                if (failed) {
-                    atomicExch(a.error_flag, 1u);
-                    sh.abort = 1;
-                }
-                StatusT* mine = static_cast<StatusT*>(a.status) + static_cast<size_t>(tile) * RADIX + tid;
-                status_store<StatusT>(mine, SB::kInclusive | static_cast<StatusT>(excl + tile_count));
-            }
-            base = a.digit_base[tid] + excl;
+    if (MODE == kModeScatter) {
+        if (tid < RADIX) sh.gbase[tid] = a.scanned[static_cast<size_t>(tid) * a.num_tiles + tile] - tile_off;
+        __syncthreads();
+    } else {
+        // Thread d owns digit d: it combines the windows of its walkers nearest first and
+        // either finishes (an inclusive prefix was reached) or moves the walk further back.
+        uint32_t excl = 0;
+        bool digit_done = tile == 0 || (kAblate & 1);
+        int next = static_cast<int>(tile) - 1;  // nearest predecessor not yet accounted for
+        unsigned long long t0 = 0;
+        uint32_t spins = 0;
+        // The first windows were requested before the payload; loads return in order, so
+        // reducing them here (outside the loop) waits for them alone.
+        if (walker) {
+            uint32_t info = 0;
+            const uint32_t sum = window_reduce<StatusT, J>(lbv, &info);
+            sh.lb_sum[lb_group][lb_digit] = sum;
+            sh.lb_info[lb_group][lb_digit] = info;
         }
-        sh.gbase[tid] = base - tile_off;
-    }
-    __syncthreads();
-    if (MODE == kModeOnesweep) {
+        MRS_STAMP(11);
+        while (true) {
+            __syncthreads();
+#ifdef MRS_STAMPS
+            if (a.stamps && tid == 0 && a.stamps[static_cast<size_t>(tile) * 16 + 12] == 0) MRS_STAMP(12);
+#endif
+            if (tid < RADIX && !digit_done) {
+                uint32_t consumed = 0;
+#pragma unroll
+                for (int g = 0; g < GROUPS; ++g) {
+                    const uint32_t info = sh.lb_info[g][tid];
+                    excl += sh.lb_sum[g][tid];
+                    consumed += info & 0xFFFFu;
+                    if (info >> 16) { digit_done = true; break; }
+                    if ((info & 0xFFFFu) < static_cast<uint32_t>(J)) break;  // an unpublished tile ends the run
+                }
+#ifdef MRS_STAMPS
+                if (a.stamps && tid == 0) {
+                    a.stamps[static_cast<size_t>(tile) * 16 + 8] += 1;               // round trips
+                    a.stamps[static_cast<size_t>(tile) * 16 + 9] += consumed;        // tiles walked
+                    a.stamps[static_cast<size_t>(tile) * 16 + 10] += consumed == 0;  // rounds that found nothing
+                }
+#endif
+                if (digit_done) {
+                    next = -1;
+                    status_store<StatusT>(static_cast<StatusT*>(a.status) + static_cast<size_t>(tile) * RADIX + tid,
+                                          SB::kInclusive | static_cast<StatusT>(excl + tile_count));
+                } else {
+                    next -= static_cast<int>(consumed);
+                    if (consumed == 0) {
+                        ++spins;
+                        if ((spins & 63u) == 0u) {
+                            const unsigned long long now = wall_clock64();
+                            if (t0 == 0) t0 = now;
+                            if (now - t0 > kSpinTimeoutTicks ||
+                                __hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                                atomicExch(a.error_flag, 1u);
+                                sh.abort = 1;
+                            }
+                        }
+                    }
+                }
+                sh.lb_next[tid] = next;
+            }
+            if (tid < RADIX && digit_done) sh.gbase[tid] = digit_base + excl - tile_off;
+            const int pending = __syncthreads_or(tid < RADIX && !digit_done);
+            if (!pending || sh.abort) break;
+            // further back: one more round trip for the digits still open
+            if (walker) {
+                const int nt = sh.lb_next[lb_digit];
+                uint32_t info = 0, sum = 0;
+                if (nt >= 0) {
+                    window_issue<RADIX, StatusT, J>(status, nt - lb_group * J, lb_digit, lbv);
+                    sum = window_reduce<StatusT, J>(lbv, &info);
+                }
+                sh.lb_sum[lb_group][lb_digit] = sum;
+                sh.lb_info[lb_group][lb_digit] = info;
+            }
+        }
         if (sh.abort) return;  // never write through an offset that was not resolved
     }
     MRS_STAMP(6);
 
     // ---- write the keys back in slot order ---------------------------------------------
     KeyT* __restrict__ keys_out = static_cast<KeyT*>(a.keys_out);
-    uint32_t gpos[KPT];
+    // The payload in the same slot goes to the same place; the digit of the slot (a
+    // quarter of a register) is what is remembered of it.
+    PackedDigits<KPT> slot_digit;
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         const uint32_t slot = i * THREADS + tid;
+        uint32_t d = 0;
         if (FULL || slot < tile_valid) {
             const KeyT k = stage_keys[slot];
-            const uint32_t d = key_digit<MAP>(k, a.shift, a.mask, a.digit_map);
-            gpos[i] = sh.gbase[d] + slot;
-            if (kAblate & 3) gpos[i] = static_cast<uint32_t>(tile_base) + slot;
-            if (kAblate & 8) { keep_alive(k); keep_alive(gpos[i]); }
-            else keys_out[gpos[i]] = k;
+            d = key_digit<MAP>(k, a.shift, a.mask, a.digit_map);
+            uint32_t g = sh.gbase[d] + slot;
+            if (kAblate & 3) g = static_cast<uint32_t>(tile_base) + slot;
+            if (kAblate & 8) { keep_alive(k); keep_alive(g); }
+            else store_element<OFF32>(keys_out, g, k);
         }
+        slot_digit.set_fresh(i, d);
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // bounds the registers in flight
     }
 
     // ---- payload: same permutation ------------------------------------------------------
     if constexpr (HAS_VAL && !(kAblate & 4)) {
         ValT* stage_vals = reinterpret_cast<ValT*>(sh.stage);
         ValT* __restrict__ vals_out = static_cast<ValT*>(a.vals_out);
+        MRS_STAMP(13);
         __syncthreads();  // the key image is dead
 #pragma unroll
         for (int i = 0; i < KPT; ++i)
-            if (FULL || my_first + i * 64 < tile_valid) stage_vals[pos[i]] = val[i];
+            if (FULL || my_first + i * 64 < tile_valid) stage_vals[pos.get(i)] = val[i];
         __syncthreads();
+        MRS_STAMP(14);
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t slot = i * THREADS + tid;
             if (FULL || slot < tile_valid) {
                 const ValT v = stage_vals[slot];
+                uint32_t g = sh.gbase[slot_digit.get(i)] + slot;
+                if (kAblate & 3) g = static_cast<uint32_t>(tile_base) + slot;
                 if (kAblate & 8) keep_alive(v);
-                else vals_out[gpos[i]] = v;
+                else store_element<OFF32>(vals_out, g, v);
             }
+            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
     }
 #ifdef MRS_STAMPS
@@ -385,8 +526,13 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
 #endif
 }
 
+// Waves per SIMD the register allocation must leave room for.  A 512 x 32 tile holds
+// 64 KiB in LDS, so two workgroups fit a compute unit only if each wave stays within
+// 128 registers; the other shapes are left to the compiler.
+constexpr int pass_min_waves_per_simd(int threads, int kpt) { return threads == 512 && kpt == 32 ? 4 : 1; }
+
 template <int MODE, bool MAP, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
-__global__ __launch_bounds__(THREADS) void digit_pass_kernel(const PassArgs a)
+__global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) void digit_pass_kernel(const PassArgs a)
 {
     using S = PassShared<BITS, THREADS, KPT, KeyT, ValT>;
     static_assert(THREADS % 64 == 0 && THREADS >= S::RADIX, "one thread per digit is required");
@@ -401,13 +547,13 @@ __global__ __launch_bounds__(THREADS) void digit_pass_kernel(const PassArgs a)
     // a workgroup that is already running.
     if (MODE == kModeOnesweep) {
         if (tid == 0) {
-            sh.tile = atomicAdd(a.tile_counter, 1u);
+            sh.tile = a.use_ticket ? atomicAdd(a.tile_counter, 1u) : blockIdx.x;
             sh.abort = 0;
         }
     }
     for (int j = tid; j < S::WAVES * S::RADIX; j += THREADS) (&sh.wave_hist[0][0])[j] = 0;
     __syncthreads();
-    const uint32_t tile = MODE == kModeOnesweep ? sh.tile : blockIdx.x;
+    const uint32_t tile = a.first_tile + (MODE == kModeOnesweep ? sh.tile : blockIdx.x);
 #ifdef MRS_STAMPS
     if (a.stamps && tid == 0) a.stamps[static_cast<size_t>(tile) * 16 + 0] = t_begin;
 #endif
