@@ -119,7 +119,7 @@ static int launch_global_hist(const mrs_plan* p, const GlobalHistArgs& a, hipStr
 {
     const uint64_t vec = p->desc.key_words == 1 ? 4 : 2;
     uint64_t blocks = (a.n / vec + 255) / 256;
-    const uint64_t cap = static_cast<uint64_t>(p->ctx->num_cus) * 8;
+    const uint64_t cap = static_cast<uint64_t>(p->ctx->num_cus) * 16;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     if (p->desc.key_words == 1) return launch_global_histogram_u32(p->radix_bits, static_cast<int>(blocks), a, s);

@@ -47,70 +47,100 @@ struct GlobalHistArgs {
     uint32_t* ghist;           // [num_passes][RADIX], must be zero
 };
 
+// One LDS counter set per workgroup, one LDS atomic per key and pass; the pass loop is
+// unrolled at compile time (passes beyond a.num_passes are skipped by a scalar branch).
+// A wave whose lanes all hold one digit (constant high bytes, sorted or all-equal
+// input) would serialise 64 ways on one LDS word: it adds 64 from one lane instead.
 template <int BITS, typename KeyT>
 __global__ __launch_bounds__(256) void global_histogram_kernel(const GlobalHistArgs a)
 {
     constexpr int RADIX = 1 << BITS;
     constexpr int MAXP = (sizeof(KeyT) * 8 + BITS - 1) / BITS;
     constexpr int VEC = 16 / sizeof(KeyT);
+    constexpr int UNROLL = 2;  // vectors in flight per thread
     __shared__ uint32_t s_hist[MAXP * RADIX];
     for (int j = threadIdx.x; j < MAXP * RADIX; j += 256) s_hist[j] = 0;
     __syncthreads();
 
     const KeyT* __restrict__ keys = static_cast<const KeyT*>(a.keys);
     const int lane = threadIdx.x & 63;
+    const bool mapped = a.digit_map != nullptr;
 
-    auto count = [&](KeyT k, bool valid) {
-        for (uint32_t p = 0; p < a.num_passes; ++p) {
-            uint32_t d;
-            if (a.digit_map) {
-                d = a.digit_map[static_cast<uint32_t>(k >> a.begin_bit) & a.map_mask];
-            } else {
+    // full waves only
+    auto count = [&](KeyT k) {
+        if (mapped) {
+            const uint32_t d = a.digit_map[static_cast<uint32_t>(k >> a.begin_bit) & a.map_mask];
+            atomicAdd(&s_hist[d], 1u);
+            return;
+        }
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            if (p < static_cast<int>(a.num_passes)) {
                 const uint32_t shift = a.begin_bit + p * BITS;
                 const uint32_t width = a.end_bit - shift < static_cast<uint32_t>(BITS) ? a.end_bit - shift : BITS;
-                d = static_cast<uint32_t>(k >> shift) & ((1u << width) - 1u);
+                const uint32_t d = static_cast<uint32_t>(k >> shift) & ((1u << width) - 1u);
+                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+                if (__builtin_amdgcn_uicmp(d, d0, 32 /* == */) == ~0ull) {
+                    if (lane == 0) atomicAdd(&s_hist[p * RADIX + d0], 64u);
+                } else {
+                    atomicAdd(&s_hist[p * RADIX + d], 1u);
+                }
             }
-            // a wave whose lanes all hold one digit (constant high bytes, sorted
-            // or all-equal input) would serialise 64 ways on one LDS word
-            const unsigned long long act = __ballot(valid);
-            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-            const bool uniform = __ballot(valid && d == d0) == act && act == ~0ull;
-            if (uniform) {
-                if (lane == 0) atomicAdd(&s_hist[p * RADIX + d0], 64u);
-            } else if (valid) {
-                atomicAdd(&s_hist[p * RADIX + d], 1u);
-            }
+        }
+    };
+    // any subset of lanes
+    auto count_some = [&](KeyT k) {
+        if (mapped) {
+            atomicAdd(&s_hist[a.digit_map[static_cast<uint32_t>(k >> a.begin_bit) & a.map_mask]], 1u);
+            return;
+        }
+        for (uint32_t p = 0; p < a.num_passes; ++p) {
+            const uint32_t shift = a.begin_bit + p * BITS;
+            const uint32_t width = a.end_bit - shift < static_cast<uint32_t>(BITS) ? a.end_bit - shift : BITS;
+            atomicAdd(&s_hist[p * RADIX + (static_cast<uint32_t>(k >> shift) & ((1u << width) - 1u))], 1u);
+        }
+    };
+    using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
+    auto count_vec = [&](const VecT& x) {
+        count(x.x);
+        count(x.y);
+        if constexpr (sizeof(KeyT) == 4) {
+            count(x.z);
+            count(x.w);
         }
     };
 
     const unsigned long long nvec = a.n / VEC;
     const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256;
-    using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
     const VecT* __restrict__ vkeys = reinterpret_cast<const VecT*>(keys);
-    // every lane of a wave runs the same number of iterations (inactive lanes
-    // carry valid = false) because `count` uses wave-wide ballots
-    const unsigned long long first = static_cast<unsigned long long>(blockIdx.x) * 256 + threadIdx.x;
-    for (unsigned long long base = first - lane; base < nvec; base += stride) {
-        const unsigned long long v = base + lane;
-        const bool valid = v < nvec;
-        VecT x;
-        if (valid) x = vkeys[v];
+    // The wave-wide comparison in `count` needs whole waves: each wave covers 64 consecutive
+    // vectors per step, and steps that are not entirely inside the input go to count_some.
+    unsigned long long v = static_cast<unsigned long long>(blockIdx.x) * 256 + threadIdx.x;
+    const unsigned long long wave_first = v - lane;
+    unsigned long long done = 0;  // steps of this wave already counted
+    while (wave_first + (done + UNROLL - 1) * stride + 64 <= nvec) {
+        VecT x[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) x[u] = vkeys[v + (done + u) * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) count_vec(x[u]);
+        done += UNROLL;
+    }
+    while (wave_first + done * stride + 64 <= nvec) {
+        count_vec(vkeys[v + done * stride]);
+        ++done;
+    }
+    if (v + done * stride < nvec) {  // the one partial step
+        const VecT x = vkeys[v + done * stride];
+        count_some(x.x);
+        count_some(x.y);
         if constexpr (sizeof(KeyT) == 4) {
-            count(valid ? x.x : 0, valid);
-            count(valid ? x.y : 0, valid);
-            count(valid ? x.z : 0, valid);
-            count(valid ? x.w : 0, valid);
-        } else {
-            count(valid ? x.x : 0, valid);
-            count(valid ? x.y : 0, valid);
+            count_some(x.z);
+            count_some(x.w);
         }
     }
-    // tail (n not a multiple of the vector width): first wave of block 0
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        const unsigned long long i = nvec * VEC + threadIdx.x;
-        const bool valid = i < a.n;
-        count(valid ? keys[i] : 0, valid);
-    }
+    // tail (n not a multiple of the vector width): first lanes of block 0
+    if (blockIdx.x == 0 && nvec * VEC + threadIdx.x < a.n) count_some(keys[nvec * VEC + threadIdx.x]);
     __syncthreads();
     for (int j = threadIdx.x; j < static_cast<int>(a.num_passes) * RADIX; j += 256) {
         const uint32_t c = s_hist[j];
