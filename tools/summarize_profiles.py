@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def counter_means(pattern, counter):
     out = collections.defaultdict(list)
-    for path in glob.glob(pattern):
+    for path in glob.glob(pattern, recursive=True):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
                 out[r["Kernel_Name"]].append(float(r["Counter_Value"]))

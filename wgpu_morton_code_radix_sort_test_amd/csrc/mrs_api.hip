@@ -37,6 +37,7 @@ int launch_block_histogram_u64(int bits, uint32_t n, const void* keys, uint32_t 
                                uint32_t shift, uint32_t mask, uint32_t* hist, hipStream_t s);
 int launch_global_histogram_u32(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
 int launch_global_histogram_u64(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
+int probe_lds_atomic_order(bool* in_order);
 
 bool config_supported(unsigned long long n, int key_words, int payload_bytes, int digit_bits, int tile_items, int algo,
                       KernelConfig* cfg)
@@ -98,8 +99,10 @@ static uint32_t pass_mask(const mrs_plan* p, uint32_t pass)
     return (1u << width) - 1u;
 }
 
-static int launch_pass(const mrs_plan* p, int mode, const PassArgs& a, hipStream_t s)
+static int launch_pass(const mrs_plan* p, int mode, const PassArgs& args, hipStream_t s)
 {
+    PassArgs a = args;
+    a.atomic_rank = p->ctx->lds_atomics_in_lane_order;
     if (p->desc.key_words == 1)
         return launch_pass_u32(mode, p->radix_bits, p->threads, p->kpt, p->desc.payload_bytes, a, s);
     return launch_pass_u64(mode, p->radix_bits, p->threads, p->kpt, p->desc.payload_bytes, a, s);
@@ -206,9 +209,21 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(MRS_ERR_UNSUPPORTED, "mrs_context_create: device %d is %s; this library is built for gfx950 only",
                     device_id, prop.gcnArchName);
+    // Which ranking the digit passes use on this device (MRS_RANK=match skips the faster one).
+    bool in_order = false;
+    const char* rank_env = std::getenv("MRS_RANK");
+    if (!(rank_env && std::strcmp(rank_env, "match") == 0)) {
+        int prev = -1;
+        MRS_HIP_TRY(hipGetDevice(&prev));
+        MRS_HIP_TRY(hipSetDevice(device_id));
+        const int rc = probe_lds_atomic_order(&in_order);
+        MRS_HIP_TRY(hipSetDevice(prev));
+        if (rc) return rc;
+    }
     mrs_context* c = new mrs_context;
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount;
+    c->lds_atomics_in_lane_order = in_order;
     *out = c;
     return MRS_OK;
 }
@@ -425,7 +440,6 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
             a.digit_base = plan->control->ghist + static_cast<size_t>(pass) * plan->radix;
             a.status = plan->status + static_cast<size_t>(pass) * num_tiles * plan->radix * plan->status_word_bytes;
             a.wide_status = plan->status_word_bytes == 8;
-            a.num_cus = plan->ctx->num_cus;
             a.use_ticket = 1;
             a.tile_counter = &plan->control->tile_counter[pass];
             a.error_flag = plan->error_flag;
@@ -610,7 +624,6 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
     a.digit_base = plan->control->ghist;
     a.status = plan->status;
     a.wide_status = plan->status_word_bytes == 8;
-    a.num_cus = plan->ctx->num_cus;
     a.use_ticket = 1;
     a.tile_counter = &plan->control->tile_counter[0];
     a.error_flag = plan->error_flag;

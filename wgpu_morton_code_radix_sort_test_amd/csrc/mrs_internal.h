@@ -56,9 +56,9 @@ struct PassArgs {
     uint32_t wide_status;        // status words are 64-bit (inputs of 2^30 elements and more)
     uint32_t* tile_counter;      // ticket dispenser of this pass
     uint32_t* error_flag;
-    uint32_t num_cus;            // host side only: sizes the grid of the persistent kernel
-    uint32_t first_tile;         // one-tile kernel: index of the tile of workgroup 0
-    uint32_t use_ticket;         // one-tile kernel, onesweep: tile ids come from the ticket counter
+    uint32_t first_tile;         // index of the tile of workgroup 0
+    uint32_t use_ticket;         // onesweep: tile ids come from the ticket counter
+    uint32_t atomic_rank;        // host side only: rank with returning LDS atomics (kRankAtomic)
 #ifdef MRS_STAMPS
     unsigned long long* stamps;  // diagnostic builds only: [num_tiles][8] phase clocks
 #endif
@@ -82,6 +82,10 @@ struct KernelConfig {
 struct mrs_context {
     int device;
     int num_cus;
+    // Returning LDS atomics of one instruction that hit the same word are served in
+    // ascending lane order on this device (checked at creation): the digit passes may rank
+    // with them.
+    bool lds_atomics_in_lane_order;
 };
 
 struct mrs_plan {
@@ -113,17 +117,6 @@ struct mrs_plan {
 };
 
 namespace mrs {
-
-// radix kernels (mrs_radix.hip)
-int launch_block_histogram(const mrs_plan* plan, uint32_t n, const void* keys, uint32_t shift,
-                           uint32_t mask, uint32_t* hist, hipStream_t s);
-int launch_scatter(const mrs_plan* plan, const PassArgs& a, hipStream_t s);
-int launch_global_histogram(const mrs_plan* plan, uint32_t n, const void* keys,
-                            const uint8_t* digit_map, uint32_t map_shift, uint32_t map_mask,
-                            uint32_t* ghist, hipStream_t s);
-int launch_onesweep_pass(const mrs_plan* plan, const PassArgs& a, hipStream_t s);
-bool config_supported(int key_words, int payload_bytes, int digit_bits, int tile_items,
-                      int algo, KernelConfig* cfg);
 
 // scan (mrs_scan.hip)
 uint64_t scan_partials_len(uint64_t len);

@@ -11,58 +11,54 @@ namespace mrs {
 // (threads, keys per thread) shapes every key/payload combination supports:
 //   256 x 1  -- the reference's one-key-per-thread 256-key block
 //   256 x 4  -- small tiles (16-byte payloads, small inputs)
-// and the large tiles, only for payloads of at most 4 bytes:
-//   512 x 8, 512 x 16 (u32 keys only)
-template <int MODE, bool MAP, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
-int launch_pass_any(const PassArgs& a, hipStream_t s)
-{
-    return launch_pass_cfg<MODE, MAP, BITS, THREADS, KPT, KeyT, ValT>(a, s);
-}
-
-template <int MODE, bool MAP, int BITS, typename KeyT, typename ValT>
+// payloads of at most 4 bytes add 512 x 8, and 32-bit keys with such payloads the large
+// tiles 512 x 16 ... 1024 x 32.  RANK selects how keys are ranked inside a wave
+// (kRankMatch / kRankAtomic, see mrs_radix_pass.hpp); each value is compiled in a
+// translation unit of its own.
+template <int MODE, int RANK, bool MAP, int BITS, typename KeyT, typename ValT>
 int launch_pass_shape(int threads, int kpt, const PassArgs& a, hipStream_t s)
 {
-    if (threads == 256 && kpt == 1) return launch_pass_any<MODE, MAP, BITS, 256, 1, KeyT, ValT>(a, s);
-    if (threads == 256 && kpt == 4) return launch_pass_any<MODE, MAP, BITS, 256, 4, KeyT, ValT>(a, s);
+#define MRS_SHAPE(T, K) \
+    if (threads == T && kpt == K) return launch_pass_cfg<MODE, RANK, MAP, BITS, T, K, KeyT, ValT>(a, s)
+    MRS_SHAPE(256, 1);
+    MRS_SHAPE(256, 4);
     if constexpr (sizeof(ValT) <= 4) {
-        if (threads == 512 && kpt == 8) return launch_pass_any<MODE, MAP, BITS, 512, 8, KeyT, ValT>(a, s);
+        MRS_SHAPE(512, 8);
         if constexpr (sizeof(KeyT) == 4) {
-            if (threads == 512 && kpt == 16) return launch_pass_any<MODE, MAP, BITS, 512, 16, KeyT, ValT>(a, s);
-            if (threads == 256 && kpt == 16) return launch_pass_any<MODE, MAP, BITS, 256, 16, KeyT, ValT>(a, s);
-            if (threads == 256 && kpt == 32) return launch_pass_any<MODE, MAP, BITS, 256, 32, KeyT, ValT>(a, s);
-            if (threads == 1024 && kpt == 16) return launch_pass_any<MODE, MAP, BITS, 1024, 16, KeyT, ValT>(a, s);
-            if (threads == 512 && kpt == 32) return launch_pass_any<MODE, MAP, BITS, 512, 32, KeyT, ValT>(a, s);
-            if (threads == 1024 && kpt == 32) return launch_pass_any<MODE, MAP, BITS, 1024, 32, KeyT, ValT>(a, s);
-            if (threads == 1024 && kpt == 8) return launch_pass_any<MODE, MAP, BITS, 1024, 8, KeyT, ValT>(a, s);
+            MRS_SHAPE(512, 16);
+            MRS_SHAPE(512, 32);
+            MRS_SHAPE(1024, 16);
+            MRS_SHAPE(1024, 32);
         }
     }
+#undef MRS_SHAPE
     return fail(MRS_ERR_UNSUPPORTED, "no kernel for %d threads x %d keys per thread", threads, kpt);
 }
 
-template <int MODE, typename KeyT, typename ValT>
+template <int MODE, int RANK, typename KeyT, typename ValT>
 int launch_pass_bits(int bits, int threads, int kpt, const PassArgs& a, hipStream_t s)
 {
     // the bucket -> part table is only used by the partition pass (onesweep machinery)
     if constexpr (MODE == kModeOnesweep) {
         if (a.digit_map) {
-            if (bits == 4) return launch_pass_shape<MODE, true, 4, KeyT, ValT>(threads, kpt, a, s);
-            if (bits == 8) return launch_pass_shape<MODE, true, 8, KeyT, ValT>(threads, kpt, a, s);
+            if (bits == 4) return launch_pass_shape<MODE, RANK, true, 4, KeyT, ValT>(threads, kpt, a, s);
+            if (bits == 8) return launch_pass_shape<MODE, RANK, true, 8, KeyT, ValT>(threads, kpt, a, s);
         }
     }
-    if (bits == 4) return launch_pass_shape<MODE, false, 4, KeyT, ValT>(threads, kpt, a, s);
-    if (bits == 8) return launch_pass_shape<MODE, false, 8, KeyT, ValT>(threads, kpt, a, s);
+    if (bits == 4) return launch_pass_shape<MODE, RANK, false, 4, KeyT, ValT>(threads, kpt, a, s);
+    if (bits == 8) return launch_pass_shape<MODE, RANK, false, 8, KeyT, ValT>(threads, kpt, a, s);
     return fail(MRS_ERR_UNSUPPORTED, "digit_bits must be 4 or 8");
 }
 
-template <typename KeyT>
+template <typename KeyT, int RANK>
 int launch_pass_key(int mode, int bits, int threads, int kpt, int payload_bytes, const PassArgs& a,
                     hipStream_t s)
 {
 #define MRS_ROUTE(MODE)                                                                              \
     switch (payload_bytes) {                                                                         \
-        case 0: return launch_pass_bits<MODE, KeyT, NoVal>(bits, threads, kpt, a, s);                \
-        case 4: return launch_pass_bits<MODE, KeyT, uint32_t>(bits, threads, kpt, a, s);             \
-        case 16: return launch_pass_bits<MODE, KeyT, uint4>(bits, threads, kpt, a, s);               \
+        case 0: return launch_pass_bits<MODE, RANK, KeyT, NoVal>(bits, threads, kpt, a, s);          \
+        case 4: return launch_pass_bits<MODE, RANK, KeyT, uint32_t>(bits, threads, kpt, a, s);       \
+        case 16: return launch_pass_bits<MODE, RANK, KeyT, uint4>(bits, threads, kpt, a, s);         \
         default: return fail(MRS_ERR_UNSUPPORTED, "payload_bytes must be 0, 4 or 16");               \
     }
     if (mode == kModeScatter) { MRS_ROUTE(kModeScatter) }

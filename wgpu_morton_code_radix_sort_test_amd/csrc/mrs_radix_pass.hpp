@@ -31,6 +31,18 @@ struct NoVal {};
 
 enum PassMode { kModeScatter = 0, kModeOnesweep = 1 };
 
+// How a wave ranks its keys (position of a key among the keys of its wave with the same
+// digit, earlier elements first).
+//   kRankMatch : every lane finds the lanes holding its digit with one ballot per digit bit;
+//                the first of them advances the wave's counter in LDS.  About 45 vector
+//                instructions per key for 8-bit digits.
+//   kRankAtomic: one returning LDS atomic add per key on the wave's counter.  The order in
+//                which the lanes of one instruction that hit the same counter are served is
+//                not part of the ISA contract; on gfx950 it is ascending lane order, which
+//                is what stability needs.  The host verifies that on the device at context
+//                creation and uses kRankMatch if the check ever fails.
+enum RankMode { kRankMatch = 0, kRankAtomic = 1 };
+
 // Tile status word of the chained scan: the top two bits are the state, the rest a
 // digit count.  0 = not published (the words are zeroed before every sort call),
 // 1 = count of this tile alone, 2 = count of this tile and every tile before it.
@@ -232,23 +244,22 @@ struct PassShared {
     static constexpr int SCAN_WAVES = (RADIX + 63) / 64;
 
     __attribute__((aligned(16))) unsigned char stage[TILE * STAGE_ELEM];
-    // Look-back: GROUPS threads share the walk of one digit, each fetching LB_WIDTH
-    // predecessors per round trip, so that one round trip usually reaches an inclusive
-    // prefix (a dependent device-scope read costs microseconds on a busy chip).
-    static constexpr int GROUPS = THREADS / RADIX >= 4 ? 4 : (THREADS / RADIX >= 2 ? 2 : 1);
+    // Look-back: GROUPS neighbouring lanes share the walk of one digit, each fetching a
+    // window of predecessors per round trip, so that one round trip usually reaches an
+    // inclusive prefix (a dependent device-scope read costs microseconds on a busy chip).
+    static constexpr int GROUPS = 1;
 
     uint32_t wave_hist[WAVES][RADIX];  // per-wave digit counts, later per-wave bases
     uint32_t gbase[RADIX];             // global position of slot 0 of each digit, minus its tile offset
-    uint32_t lb_sum[GROUPS][RADIX];    // look-back: sum over the group's window
-    uint32_t lb_info[GROUPS][RADIX];   // look-back: words consumed | found << 16
-    int lb_next[RADIX];                // look-back: nearest predecessor not yet accounted for
+    uint32_t tile_count[RADIX];        // keys of this tile per digit
+    uint32_t tile_off[RADIX];          // keys of this tile with a smaller digit
     uint32_t wsum[SCAN_WAVES];
     uint32_t tile;
     uint32_t abort;
 };
 
 // Everything after the tile id is known.  FULL = the tile has TILE valid elements.
-template <int MODE, bool MAP, bool FULL, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT,
+template <int MODE, int RANK, bool MAP, bool FULL, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT,
           typename ValT>
 __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS, THREADS, KPT, KeyT, ValT>& sh,
                                              const uint32_t tile, const uint32_t tile_valid)
@@ -286,23 +297,29 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
 
     // ---- rank inside the wave ------------------------------------------------------
     // pos[i] = number of earlier elements of this wave with the same digit.
-    // wave_hist[wave][d] carries the running count; the lowest lane of each digit
-    // group advances it.  LDS operations of one wave execute in order, so the read
-    // of item i+1 sees the update of item i.
+    // wave_hist[wave][d] carries the running count.  LDS operations of one wave execute
+    // in order, so item i+1 sees the update of item i.
     PackedPos<KPT> pos;
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         if (kAblate & 2) { pos.set_fresh(i, 0); continue; }
         const uint32_t d = key_digit<MAP>(key[i], a.shift, a.mask, a.digit_map);
-        const unsigned long long valid = FULL ? ~0ull : __ballot(my_first + i * 64 < tile_valid);
-        uint32_t mlo, mhi;
-        match_digit<BITS>(d, valid, &mlo, &mhi);
-        const uint32_t below = lanes_below(mlo, mhi);
-        const uint32_t prev = sh.wave_hist[wave][d];
         const bool mine = FULL || (my_first + i * 64 < tile_valid);
-        if (mine && below == 0) sh.wave_hist[wave][d] = prev + __popc(mlo) + __popc(mhi);
-        pos.set_fresh(i, prev + below);
-        __builtin_amdgcn_wave_barrier();
+        if constexpr (RANK == kRankAtomic) {
+            uint32_t r = 0;
+            if (mine) r = atomicAdd(&sh.wave_hist[wave][d], 1u);
+            pos.set_fresh(i, r);
+        } else {
+            // the lowest lane of each digit group advances the counter
+            const unsigned long long valid = FULL ? ~0ull : __ballot(mine);
+            uint32_t mlo, mhi;
+            match_digit<BITS>(d, valid, &mlo, &mhi);
+            const uint32_t below = lanes_below(mlo, mhi);
+            const uint32_t prev = sh.wave_hist[wave][d];
+            if (mine && below == 0) sh.wave_hist[wave][d] = prev + __popc(mlo) + __popc(mhi);
+            pos.set_fresh(i, prev + below);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     // The digits and counter addresses of the ranking are cheap to recompute and costly to
     // keep: hide the keys' provenance so that the staging below does not keep them alive.
@@ -343,24 +360,33 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
         tile_off += incl - tile_count;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sh.wave_hist[w][tid] += tile_off;
+        sh.tile_count[tid] = tile_count;
+        sh.tile_off[tid] = tile_off;
     }
     __syncthreads();
     MRS_STAMP(4);
 
     // ---- look-back, first round trip ------------------------------------------------------
-    // Requested by every wave before any wave asks for the payload: a status read that
-    // queues behind the payload loads of the whole workgroup comes back microseconds
-    // later.  The staging of the keys below covers part of the round trip.
+    // Lanes GROUPS*d .. GROUPS*d + GROUPS-1 walk digit d: lane g fetches the J predecessors
+    // from tile-1 - g*J downwards.  The windows are requested by every wave before any wave
+    // asks for the payload: a status read that queues behind the payload loads of the whole
+    // workgroup comes back microseconds later.  The staging of the keys covers part of
+    // the round trip.
     constexpr int GROUPS = S::GROUPS;
     // tiles of 32 keys per thread are half as many: half the window reaches as far back in time
-    constexpr int J = KPT >= 32 ? SB::kWidth / 2 : SB::kWidth;
-    const int lb_group = tid / RADIX;
-    const uint32_t lb_digit = tid % RADIX;
+    constexpr int J = KPT >= 32 ? SB::kWidth : SB::kWidth * 2;
+    const bool in_walk = MODE == kModeOnesweep && tid < RADIX * GROUPS;
+    const uint32_t lb_digit = tid / GROUPS;
+    const int lb_group = tid % GROUPS;
     const StatusT* const status = static_cast<const StatusT*>(a.status);
-    // digit d's first output position in the whole array (needed at the end of the look-back)
-    uint32_t digit_base = 0;
-    if (MODE == kModeOnesweep && tid < RADIX) digit_base = a.digit_base[tid];
-    const bool walker = MODE == kModeOnesweep && !(kAblate & 1) && tile != 0 && lb_group < GROUPS;
+    const bool walker = in_walk && !(kAblate & 1) && tile != 0;
+    // of the walked digit: first output position in the whole array, count and offset in this tile
+    uint32_t digit_base = 0, walk_count = 0, walk_off = 0;
+    if (in_walk) {
+        digit_base = a.digit_base[lb_digit];
+        walk_count = sh.tile_count[lb_digit];
+        walk_off = sh.tile_off[lb_digit];
+    }
     StatusT lbv[J];
     if (walker) window_issue<RADIX, StatusT, J>(status, static_cast<int>(tile) - 1 - lb_group * J, lb_digit, lbv);
 
@@ -395,82 +421,83 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     // ---- global base of every digit of this tile ------------------------------------
     if (MODE == kModeScatter) {
         if (tid < RADIX) sh.gbase[tid] = a.scanned[static_cast<size_t>(tid) * a.num_tiles + tile] - tile_off;
-        __syncthreads();
     } else {
-        // Thread d owns digit d: it combines the windows of its walkers nearest first and
-        // either finishes (an inclusive prefix was reached) or moves the walk further back.
+        // Every wave resolves its own digits without waiting for the other waves: the sooner
+        // an inclusive prefix is published, the shorter the walks of the tiles behind.
         uint32_t excl = 0;
-        bool digit_done = tile == 0 || (kAblate & 1);
+        bool done = !walker;
         int next = static_cast<int>(tile) - 1;  // nearest predecessor not yet accounted for
         unsigned long long t0 = 0;
         uint32_t spins = 0;
-        // The first windows were requested before the payload; loads return in order, so
-        // reducing them here (outside the loop) waits for them alone.
-        if (walker) {
-            uint32_t info = 0;
-            const uint32_t sum = window_reduce<StatusT, J>(lbv, &info);
-            sh.lb_sum[lb_group][lb_digit] = sum;
-            sh.lb_info[lb_group][lb_digit] = info;
-        }
-        MRS_STAMP(11);
-        while (true) {
-            __syncthreads();
-#ifdef MRS_STAMPS
-            if (a.stamps && tid == 0 && a.stamps[static_cast<size_t>(tile) * 16 + 12] == 0) MRS_STAMP(12);
-#endif
-            if (tid < RADIX && !digit_done) {
-                uint32_t consumed = 0;
+        // One round for the windows held in lbv: reduce, combine the group's windows nearest
+        // first, then publish or move the walk further back.
+        auto resolve_round = [&]() {
+            uint32_t info = 0, sum = 0;
+            if (!done) sum = window_reduce<StatusT, J>(lbv, &info);
+            uint32_t consumed = 0;
+            bool found = false, open = true;
 #pragma unroll
-                for (int g = 0; g < GROUPS; ++g) {
-                    const uint32_t info = sh.lb_info[g][tid];
-                    excl += sh.lb_sum[g][tid];
-                    consumed += info & 0xFFFFu;
-                    if (info >> 16) { digit_done = true; break; }
-                    if ((info & 0xFFFFu) < static_cast<uint32_t>(J)) break;  // an unpublished tile ends the run
-                }
-#ifdef MRS_STAMPS
-                if (a.stamps && tid == 0) {
-                    a.stamps[static_cast<size_t>(tile) * 16 + 8] += 1;               // round trips
-                    a.stamps[static_cast<size_t>(tile) * 16 + 9] += consumed;        // tiles walked
-                    a.stamps[static_cast<size_t>(tile) * 16 + 10] += consumed == 0;  // rounds that found nothing
-                }
-#endif
-                if (digit_done) {
-                    next = -1;
-                    status_store<StatusT>(static_cast<StatusT*>(a.status) + static_cast<size_t>(tile) * RADIX + tid,
-                                          SB::kInclusive | static_cast<StatusT>(excl + tile_count));
-                } else {
-                    next -= static_cast<int>(consumed);
-                    if (consumed == 0) {
-                        ++spins;
-                        if ((spins & 63u) == 0u) {
-                            const unsigned long long now = wall_clock64();
-                            if (t0 == 0) t0 = now;
-                            if (now - t0 > kSpinTimeoutTicks ||
-                                __hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                                atomicExch(a.error_flag, 1u);
-                                sh.abort = 1;
-                            }
-                        }
+            for (int g = 0; g < GROUPS; ++g) {
+                const int src = (lane & ~(GROUPS - 1)) + g;
+                const uint32_t s_g = GROUPS == 1 ? sum : __shfl(sum, src);
+                const uint32_t i_g = GROUPS == 1 ? info : __shfl(info, src);
+                if (open) {
+                    excl += s_g;
+                    consumed += i_g & 0xFFFFu;
+                    if (i_g >> 16) {
+                        found = true;
+                        open = false;
+                    } else if ((i_g & 0xFFFFu) < static_cast<uint32_t>(J)) {
+                        open = false;  // an unpublished tile ends the run
                     }
                 }
-                sh.lb_next[tid] = next;
             }
-            if (tid < RADIX && digit_done) sh.gbase[tid] = digit_base + excl - tile_off;
-            const int pending = __syncthreads_or(tid < RADIX && !digit_done);
-            if (!pending || sh.abort) break;
-            // further back: one more round trip for the digits still open
-            if (walker) {
-                const int nt = sh.lb_next[lb_digit];
-                uint32_t info = 0, sum = 0;
-                if (nt >= 0) {
-                    window_issue<RADIX, StatusT, J>(status, nt - lb_group * J, lb_digit, lbv);
-                    sum = window_reduce<StatusT, J>(lbv, &info);
+            if (done) return;
+#ifdef MRS_STAMPS
+            if (a.stamps && tid == 0) {
+                a.stamps[static_cast<size_t>(tile) * 16 + 8] += 1;               // round trips
+                a.stamps[static_cast<size_t>(tile) * 16 + 9] += consumed;        // tiles walked
+                a.stamps[static_cast<size_t>(tile) * 16 + 10] += consumed == 0;  // rounds that found nothing
+            }
+#endif
+            if (found) {
+                done = true;
+                if (lb_group == 0) {
+                    status_store<StatusT>(static_cast<StatusT*>(a.status) + static_cast<size_t>(tile) * RADIX + lb_digit,
+                                          SB::kInclusive | static_cast<StatusT>(excl + walk_count));
+                    sh.gbase[lb_digit] = digit_base + excl - walk_off;
                 }
-                sh.lb_sum[lb_group][lb_digit] = sum;
-                sh.lb_info[lb_group][lb_digit] = info;
+                return;
             }
+            next -= static_cast<int>(consumed);
+            if (consumed == 0) {
+                ++spins;
+                if ((spins & 63u) == 0u) {
+                    const unsigned long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > kSpinTimeoutTicks ||
+                        __hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                        atomicExch(a.error_flag, 1u);
+                        sh.abort = 1;
+                        done = true;  // gives up; nothing is written through the unresolved offset
+                    }
+                }
+            }
+        };
+        // The first windows were requested before the payload; loads return in order, so
+        // reducing them here (outside the loop) waits for them alone.
+        if (__ballot(!done) != 0ull) resolve_round();
+        MRS_STAMP(11);
+        while (__ballot(!done) != 0ull) {
+            if (!done) window_issue<RADIX, StatusT, J>(status, next - lb_group * J, lb_digit, lbv);
+            resolve_round();
         }
+        // tile 0 has nothing before it
+        if (in_walk && !walker && lb_group == 0) sh.gbase[lb_digit] = digit_base - walk_off;
+        MRS_STAMP(12);
+    }
+    __syncthreads();
+    if (MODE == kModeOnesweep) {
         if (sh.abort) return;  // never write through an offset that was not resolved
     }
     MRS_STAMP(6);
@@ -531,7 +558,7 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
 // 128 registers; the other shapes are left to the compiler.
 constexpr int pass_min_waves_per_simd(int threads, int kpt) { return threads == 512 && kpt == 32 ? 4 : 1; }
 
-template <int MODE, bool MAP, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
+template <int MODE, int RANK, bool MAP, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
 __global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) void digit_pass_kernel(const PassArgs a)
 {
     using S = PassShared<BITS, THREADS, KPT, KeyT, ValT>;
@@ -564,20 +591,20 @@ __global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) voi
                                     ? static_cast<uint32_t>(a.n - tile_base)
                                     : S::TILE;
     if (tile_valid == S::TILE)
-        process_tile<MODE, MAP, true, StatusT>(a, sh, tile, tile_valid);
+        process_tile<MODE, RANK, MAP, true, StatusT>(a, sh, tile, tile_valid);
     else
-        process_tile<MODE, MAP, false, StatusT>(a, sh, tile, tile_valid);
+        process_tile<MODE, RANK, MAP, false, StatusT>(a, sh, tile, tile_valid);
 }
 
-template <int MODE, bool MAP, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
+template <int MODE, int RANK, bool MAP, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
 int launch_pass_cfg(const PassArgs& a, hipStream_t s)
 {
     // 32-bit status words hold counts below 2^30; the scatter mode has no status words
     if (MODE == kModeOnesweep && a.wide_status)
-        hipLaunchKernelGGL((digit_pass_kernel<MODE, MAP, unsigned long long, BITS, THREADS, KPT, KeyT, ValT>),
+        hipLaunchKernelGGL((digit_pass_kernel<MODE, RANK, MAP, unsigned long long, BITS, THREADS, KPT, KeyT, ValT>),
                            dim3(a.num_tiles), dim3(THREADS), 0, s, a);
     else
-        hipLaunchKernelGGL((digit_pass_kernel<MODE, MAP, uint32_t, BITS, THREADS, KPT, KeyT, ValT>),
+        hipLaunchKernelGGL((digit_pass_kernel<MODE, RANK, MAP, uint32_t, BITS, THREADS, KPT, KeyT, ValT>),
                            dim3(a.num_tiles), dim3(THREADS), 0, s, a);
     MRS_CHECK_LAUNCH("digit_pass_kernel");
     return MRS_OK;
