@@ -4,8 +4,9 @@
     MRS_LIBRARY_PATH=scratch/libmrs_diag.so python3 tools/phase_stamps.py --log2n 28
 
 Stamps (100 MHz clock, thread 0 of every tile of pass 1):
- 0 kernel entry  1 ticket known  2 keys+payload loaded  3 ranked  4 digit offsets ready
- 5 keys staged in LDS  6 look-back done  7 all stores retired
+ 0 kernel entry  1 ticket known  2 keys loaded  3 ranked  4 digit offsets ready
+ 5 look-back done, keys staged in LDS, payload requested  6 workgroup barrier passed
+ 7 all stores retired
 """
 import argparse
 import ctypes
@@ -18,7 +19,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wgpu_morton_code_radix_sort_test_amd as mrs  # noqa: E402
 
-NAMES = ["-", "key wait", "rank", "hist+bases", "stage+issue", "lookback", "write_out"]
+NAMES = ["-", "key wait", "rank", "hist+bases", "lookback+stage", "barrier wait", "write_out"]
 
 
 def main():
@@ -52,16 +53,17 @@ def main():
         col = d[:, k]
         print(f"{name:12s} mean {col.mean():8.2f}  p10 {np.percentile(col, 10):8.2f}  p50 {np.percentile(col, 50):8.2f}  "
               f"p90 {np.percentile(col, 90):8.2f}  max {col.max():8.2f}")
-    # finer stamps: 11 first look-back words reduced, 12 first look-back barrier passed,
+    # finer stamps: 11 first look-back round reduced, 12 look-back finished (thread 0's wave),
     # 13 key stores issued, 14 payload staged in LDS
     fine = raw[:, 11:15].astype(np.float64) / 100.0
     have = raw[:, 11] != 0
     if have.any():
-        for name, col in (("  lb words in", fine[:, 0] - st[:, 5]), ("  lb barrier", fine[:, 1] - fine[:, 0]),
-                          ("  lb combine", st[:, 6] - fine[:, 1]), ("  key stores", fine[:, 2] - st[:, 6]),
-                          ("  val staged", fine[:, 3] - fine[:, 2]), ("  val stores", st[:, 7] - fine[:, 3])):
+        for name, col in (("  lb round 1", fine[:, 0] - st[:, 4]), ("  lb more rounds", fine[:, 1] - fine[:, 0]),
+                          ("  stage+val issue", st[:, 5] - fine[:, 1]), ("  barrier wait", st[:, 6] - st[:, 5]),
+                          ("  key stores", fine[:, 2] - st[:, 6]), ("  val staged", fine[:, 3] - fine[:, 2]),
+                          ("  val stores", st[:, 7] - fine[:, 3])):
             col = col[have]
-            print(f"{name:14s} mean {col.mean():8.2f}  p10 {np.percentile(col, 10):8.2f}  p50 {np.percentile(col, 50):8.2f}  "
+            print(f"{name:18s} mean {col.mean():8.2f}  p10 {np.percentile(col, 10):8.2f}  p50 {np.percentile(col, 50):8.2f}  "
                   f"p90 {np.percentile(col, 90):8.2f}")
     life = st[:, 7] - st[:, 0]
     print(f"{'tile life':12s} mean {life.mean():8.2f}  p50 {np.percentile(life, 50):8.2f}  p90 {np.percentile(life, 90):8.2f}")

@@ -444,7 +444,8 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
             a.tile_counter = &plan->control->tile_counter[pass];
             a.error_flag = plan->error_flag;
 #ifdef MRS_STAMPS
-            a.stamps = pass == 1 ? g_debug_stamps : nullptr;
+            static const uint32_t stamp_pass = std::getenv("MRS_STAMP_PASS") ? std::atoi(std::getenv("MRS_STAMP_PASS")) : 1;
+            a.stamps = pass == stamp_pass ? g_debug_stamps : nullptr;
 #endif
             if (int rc = launch_pass(plan, kModeOnesweep, a, s)) return rc;
             if (int rc = mark(plan, "onesweep_pass", s)) return rc;

@@ -208,10 +208,20 @@ struct PackedPos {
     // first write of element i; the elements are written in ascending order
     __device__ __forceinline__ void set_fresh(int i, uint32_t v)
     {
-        if (i & 1) w[i / 2] |= v << 16;
-        else w[i / 2] = v;
+        if (i & 1) {
+            w[i / 2] |= v << 16;
+            asm volatile("" : "+v"(w[i / 2]));  // as in set_pair
+        } else {
+            w[i / 2] = v;
+        }
     }
-    __device__ __forceinline__ void set_pair(int j, uint32_t lo, uint32_t hi) { w[j] = lo | (hi << 16); }
+    // The word is hidden from the optimiser, which would otherwise keep both halves in
+    // registers of their own and undo the packing.
+    __device__ __forceinline__ void set_pair(int j, uint32_t lo, uint32_t hi)
+    {
+        w[j] = lo | (hi << 16);
+        asm volatile("" : "+v"(w[j]));
+    }
     // overwrite of element i, the other half kept
     __device__ __forceinline__ void set(int i, uint32_t v)
     {
@@ -230,6 +240,9 @@ struct PackedDigits {
     {
         if (i & 3) w[i / 4] |= d << (8 * (i & 3));
         else w[i / 4] = d;
+        // a complete word is hidden from the optimiser, which would otherwise keep the
+        // digits in registers of their own
+        if ((i & 3) == 3 || i == N - 1) asm volatile("" : "+v"(w[i / 4]));
     }
 };
 
@@ -244,15 +257,8 @@ struct PassShared {
     static constexpr int SCAN_WAVES = (RADIX + 63) / 64;
 
     __attribute__((aligned(16))) unsigned char stage[TILE * STAGE_ELEM];
-    // Look-back: GROUPS neighbouring lanes share the walk of one digit, each fetching a
-    // window of predecessors per round trip, so that one round trip usually reaches an
-    // inclusive prefix (a dependent device-scope read costs microseconds on a busy chip).
-    static constexpr int GROUPS = 1;
-
     uint32_t wave_hist[WAVES][RADIX];  // per-wave digit counts, later per-wave bases
     uint32_t gbase[RADIX];             // global position of slot 0 of each digit, minus its tile offset
-    uint32_t tile_count[RADIX];        // keys of this tile per digit
-    uint32_t tile_off[RADIX];          // keys of this tile with a smaller digit
     uint32_t wsum[SCAN_WAVES];
     uint32_t tile;
     uint32_t abort;
@@ -360,63 +366,35 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
         tile_off += incl - tile_count;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sh.wave_hist[w][tid] += tile_off;
-        sh.tile_count[tid] = tile_count;
-        sh.tile_off[tid] = tile_off;
     }
     __syncthreads();
     MRS_STAMP(4);
 
     // ---- look-back, first round trip ------------------------------------------------------
-    // Lanes GROUPS*d .. GROUPS*d + GROUPS-1 walk digit d: lane g fetches the J predecessors
-    // from tile-1 - g*J downwards.  The windows are requested by every wave before any wave
-    // asks for the payload: a status read that queues behind the payload loads of the whole
-    // workgroup comes back microseconds later.  The staging of the keys covers part of
-    // the round trip.
-    constexpr int GROUPS = S::GROUPS;
-    // tiles of 32 keys per thread are half as many: half the window reaches as far back in time
-    constexpr int J = KPT >= 32 ? SB::kWidth : SB::kWidth * 2;
-    const bool in_walk = MODE == kModeOnesweep && tid < RADIX * GROUPS;
-    const uint32_t lb_digit = tid / GROUPS;
-    const int lb_group = tid % GROUPS;
+    // Thread d fetches the status words of digit d of the J tiles before this one.  These
+    // waves resolve the look-back and publish the inclusive prefix BEFORE they stage their
+    // keys: every microsecond between the arrival of the status words and the publication
+    // adds tiles to the walk of every successor.  The other waves stage their keys
+    // meanwhile, so the LDS stays busy, and no wave has asked for the payload yet (a status
+    // read that queues behind the payload loads of the workgroup comes back microseconds
+    // later).  A dependent device-scope read costs microseconds on a busy chip and as many
+    // tiles enter look-back meanwhile, hence a window of J predecessors per round trip.
+#ifdef MRS_LB_WIDTH
+    constexpr int J = MRS_LB_WIDTH;
+#else
+    // tiles of 32 keys per thread leave fewer registers for the window
+    constexpr int J = KPT >= 32 ? SB::kWidth * 3 / 2 : SB::kWidth * 2;
+#endif
+    const bool in_walk = MODE == kModeOnesweep && tid < RADIX;
+    const uint32_t lb_digit = tid;
     const StatusT* const status = static_cast<const StatusT*>(a.status);
     const bool walker = in_walk && !(kAblate & 1) && tile != 0;
     // of the walked digit: first output position in the whole array, count and offset in this tile
-    uint32_t digit_base = 0, walk_count = 0, walk_off = 0;
-    if (in_walk) {
-        digit_base = a.digit_base[lb_digit];
-        walk_count = sh.tile_count[lb_digit];
-        walk_off = sh.tile_off[lb_digit];
-    }
+    uint32_t digit_base = 0;
+    const uint32_t walk_count = tile_count, walk_off = tile_off;
+    if (in_walk) digit_base = a.digit_base[lb_digit];
     StatusT lbv[J];
-    if (walker) window_issue<RADIX, StatusT, J>(status, static_cast<int>(tile) - 1 - lb_group * J, lb_digit, lbv);
-
-    // ---- local sort of the keys through LDS ---------------------------------------
-    KeyT* stage_keys = reinterpret_cast<KeyT*>(sh.stage);
-#pragma unroll
-    for (int i = 0; i < KPT; i += 2) {
-        uint32_t p[2] = {0, 0};
-#pragma unroll
-        for (int h = 0; h < 2 && i + h < KPT; ++h) {
-            const uint32_t d = key_digit<MAP>(key[i + h], a.shift, a.mask, a.digit_map);
-            p[h] = pos.get(i + h) + sh.wave_hist[wave][d];
-            if (kAblate & 2) p[h] = my_first + (i + h) * 64;
-            if (FULL || my_first + (i + h) * 64 < tile_valid) stage_keys[p[h]] = key[i + h];
-        }
-        pos.set_pair(i / 2, p[0], p[1]);
-        if ((i & 7) == 6) __builtin_amdgcn_sched_barrier(0);  // bounds the registers in flight
-    }
-    // The payload is fetched now: its latency hides behind the look-back, and its
-    // registers take over from the keys, which live in LDS from here on.
-    ValT val[KPT];
-    if constexpr (HAS_VAL) {
-        if (!(kAblate & 4)) {
-            const ValT* __restrict__ vals_in = static_cast<const ValT*>(a.vals_in) + tile_base + my_first;
-#pragma unroll
-            for (int i = 0; i < KPT; ++i)
-                if (FULL || my_first + i * 64 < tile_valid) val[i] = vals_in[i * 64];
-        }
-    }
-    MRS_STAMP(5);
+    if (walker) window_issue<RADIX, StatusT, J>(status, static_cast<int>(tile) - 1, lb_digit, lbv);
 
     // ---- global base of every digit of this tile ------------------------------------
     if (MODE == kModeScatter) {
@@ -429,30 +407,13 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
         int next = static_cast<int>(tile) - 1;  // nearest predecessor not yet accounted for
         unsigned long long t0 = 0;
         uint32_t spins = 0;
-        // One round for the windows held in lbv: reduce, combine the group's windows nearest
-        // first, then publish or move the walk further back.
+        // The window held in lbv is reduced; then publish, or move the walk further back.
         auto resolve_round = [&]() {
-            uint32_t info = 0, sum = 0;
-            if (!done) sum = window_reduce<StatusT, J>(lbv, &info);
-            uint32_t consumed = 0;
-            bool found = false, open = true;
-#pragma unroll
-            for (int g = 0; g < GROUPS; ++g) {
-                const int src = (lane & ~(GROUPS - 1)) + g;
-                const uint32_t s_g = GROUPS == 1 ? sum : __shfl(sum, src);
-                const uint32_t i_g = GROUPS == 1 ? info : __shfl(info, src);
-                if (open) {
-                    excl += s_g;
-                    consumed += i_g & 0xFFFFu;
-                    if (i_g >> 16) {
-                        found = true;
-                        open = false;
-                    } else if ((i_g & 0xFFFFu) < static_cast<uint32_t>(J)) {
-                        open = false;  // an unpublished tile ends the run
-                    }
-                }
-            }
             if (done) return;
+            uint32_t info = 0;
+            excl += window_reduce<StatusT, J>(lbv, &info);
+            const uint32_t consumed = info & 0xFFFFu;
+            const bool found = (info >> 16) != 0u;
 #ifdef MRS_STAMPS
             if (a.stamps && tid == 0) {
                 a.stamps[static_cast<size_t>(tile) * 16 + 8] += 1;               // round trips
@@ -462,11 +423,9 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
 #endif
             if (found) {
                 done = true;
-                if (lb_group == 0) {
-                    status_store<StatusT>(static_cast<StatusT*>(a.status) + static_cast<size_t>(tile) * RADIX + lb_digit,
-                                          SB::kInclusive | static_cast<StatusT>(excl + walk_count));
-                    sh.gbase[lb_digit] = digit_base + excl - walk_off;
-                }
+                status_store<StatusT>(static_cast<StatusT*>(a.status) + static_cast<size_t>(tile) * RADIX + lb_digit,
+                                      SB::kInclusive | static_cast<StatusT>(excl + walk_count));
+                sh.gbase[lb_digit] = digit_base + excl - walk_off;
                 return;
             }
             next -= static_cast<int>(consumed);
@@ -484,18 +443,44 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
                 }
             }
         };
-        // The first windows were requested before the payload; loads return in order, so
-        // reducing them here (outside the loop) waits for them alone.
-        if (__ballot(!done) != 0ull) resolve_round();
+        resolve_round();
         MRS_STAMP(11);
         while (__ballot(!done) != 0ull) {
-            if (!done) window_issue<RADIX, StatusT, J>(status, next - lb_group * J, lb_digit, lbv);
+            if (!done) window_issue<RADIX, StatusT, J>(status, next, lb_digit, lbv);
             resolve_round();
         }
         // tile 0 has nothing before it
-        if (in_walk && !walker && lb_group == 0) sh.gbase[lb_digit] = digit_base - walk_off;
+        if (in_walk && !walker) sh.gbase[lb_digit] = digit_base - walk_off;
         MRS_STAMP(12);
     }
+    // ---- local sort of the keys through LDS ---------------------------------------
+    KeyT* stage_keys = reinterpret_cast<KeyT*>(sh.stage);
+#pragma unroll
+    for (int i = 0; i < KPT; i += 2) {
+        uint32_t p[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2 && i + h < KPT; ++h) {
+            const uint32_t d = key_digit<MAP>(key[i + h], a.shift, a.mask, a.digit_map);
+            p[h] = pos.get(i + h) + sh.wave_hist[wave][d];
+            if (kAblate & 2) p[h] = my_first + (i + h) * 64;
+            if (FULL || my_first + (i + h) * 64 < tile_valid) stage_keys[p[h]] = key[i + h];
+        }
+        pos.set_pair(i / 2, p[0], p[1]);
+        if ((i & 7) == 6) __builtin_amdgcn_sched_barrier(0);  // bounds the registers in flight
+    }
+    // The payload is fetched now: its latency hides behind the key write-out, and its
+    // registers take over from the keys, which live in LDS from here on.
+    ValT val[KPT];
+    if constexpr (HAS_VAL) {
+        if (!(kAblate & 4)) {
+            const ValT* __restrict__ vals_in = static_cast<const ValT*>(a.vals_in) + tile_base + my_first;
+#pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                if (FULL || my_first + i * 64 < tile_valid) val[i] = vals_in[i * 64];
+        }
+    }
+
+    MRS_STAMP(5);
     __syncthreads();
     if (MODE == kModeOnesweep) {
         if (sh.abort) return;  // never write through an offset that was not resolved
@@ -600,12 +585,13 @@ template <int MODE, int RANK, bool MAP, int BITS, int THREADS, int KPT, typename
 int launch_pass_cfg(const PassArgs& a, hipStream_t s)
 {
     // 32-bit status words hold counts below 2^30; the scatter mode has no status words
-    if (MODE == kModeOnesweep && a.wide_status)
-        hipLaunchKernelGGL((digit_pass_kernel<MODE, RANK, MAP, unsigned long long, BITS, THREADS, KPT, KeyT, ValT>),
-                           dim3(a.num_tiles), dim3(THREADS), 0, s, a);
+    auto wide = digit_pass_kernel<MODE, RANK, MAP, unsigned long long, BITS, THREADS, KPT, KeyT, ValT>;
+    auto narrow = digit_pass_kernel<MODE, RANK, MAP, uint32_t, BITS, THREADS, KPT, KeyT, ValT>;
+    const bool use_wide = MODE == kModeOnesweep && a.wide_status;
+    if (use_wide)
+        hipLaunchKernelGGL(wide, dim3(a.num_tiles), dim3(THREADS), 0, s, a);
     else
-        hipLaunchKernelGGL((digit_pass_kernel<MODE, RANK, MAP, uint32_t, BITS, THREADS, KPT, KeyT, ValT>),
-                           dim3(a.num_tiles), dim3(THREADS), 0, s, a);
+        hipLaunchKernelGGL(narrow, dim3(a.num_tiles), dim3(THREADS), 0, s, a);
     MRS_CHECK_LAUNCH("digit_pass_kernel");
     return MRS_OK;
 }
