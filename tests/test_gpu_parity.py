@@ -166,6 +166,30 @@ def test_sort_tile_shapes(ctx, oracle, mrs, tile, algo_name):
     assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
 
 
+@pytest.mark.parametrize("tile", [256, 1024, 4096, 8192])
+@pytest.mark.parametrize("algo_name", ["three_kernel", "onesweep"])
+def test_sort_tile_shapes_triangle_payload(ctx, oracle, mrs, tile, algo_name):
+    """The reference's element type: 64-bit code, 16-byte TriangleIndices payload."""
+    algo = mrs.ALGO_ONESWEEP if algo_name == "onesweep" else mrs.ALGO_THREE_KERNEL
+    n = 9 * tile + 5
+    keys = make_keys(oracle, n, 2, "random")
+    vals = make_vals(oracle, n, 4)
+    ko, vo, _ = gpu_sort(ctx, mrs, keys, vals, n, 2, 4, 8, 0, 64, algo, tile_items=tile)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 2, 4, 0, 64)
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+def test_sort_large_tile_u64_keys(ctx, oracle, mrs):
+    """64-bit keys with a 4-byte payload on the 16384-element tile."""
+    n = 7 * 16384 + 3
+    keys = make_keys(oracle, n, 2, "random")
+    vals = make_vals(oracle, n, 1)
+    for algo in (mrs.ALGO_THREE_KERNEL, mrs.ALGO_ONESWEEP):
+        ko, vo, _ = gpu_sort(ctx, mrs, keys, vals, n, 2, 1, 8, 0, 64, algo, tile_items=16384)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 2, 1, 0, 64)
+        assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
 @pytest.mark.parametrize("tile", [256, 1024])
 @pytest.mark.parametrize("dist", ["random", "all_equal"])
 def test_onesweep_long_chains(ctx, oracle, mrs, tile, dist):
@@ -304,7 +328,9 @@ def test_errors_are_reported(ctx, mrs):
     with pytest.raises(mrs.MrsError):
         mrs.SortPlan(ctx, 0)
     with pytest.raises(mrs.MrsError):
-        mrs.SortPlan(ctx, 1000, key_words=1, payload_bytes=16, tile_items=8192)
+        mrs.SortPlan(ctx, 1000, key_words=1, payload_bytes=16, tile_items=16384)
+    with pytest.raises(mrs.MrsError):
+        mrs.SortPlan(ctx, 1000, key_words=2, payload_bytes=4, tile_items=8192)
     plan = mrs.SortPlan(ctx, 1000)
     k = torch.zeros(2000, dtype=torch.int32, device=ctx.device)
     with pytest.raises(mrs.MrsError):

@@ -46,14 +46,14 @@ bool config_supported(unsigned long long n, int key_words, int payload_bytes, in
     if (key_words != 1 && key_words != 2) return false;
     if (payload_bytes != 0 && payload_bytes != 4 && payload_bytes != 16) return false;
     if (digit_bits != 4 && digit_bits != 8) return false;
-    const bool small_pairs = key_words == 1 && payload_bytes <= 4;  // the shapes of 8192 elements and more
+    const bool small_pairs = key_words == 1 && payload_bytes <= 4;  // the shapes of 16384 elements and more
     KernelConfig c;
     switch (tile_items) {
         case 0:
             // Larger tiles scatter longer runs per digit and walk fewer tile status words, as
             // long as the input still yields several tiles per compute unit.
-            if (payload_bytes == 16) c = {256, 4};
-            else if (key_words == 2) c = {512, 8};
+            if (payload_bytes == 16) c = n >= (1ull << 23) ? KernelConfig{1024, 8} : (n >= (1ull << 20) ? KernelConfig{512, 8} : KernelConfig{256, 4});
+            else if (key_words == 2) c = n >= (1ull << 24) ? KernelConfig{1024, 16} : KernelConfig{512, 8};
             else if (n >= (1ull << 25)) c = {1024, 32};
             else if (n >= (1ull << 24)) c = {1024, 16};
             else c = {512, 16};
@@ -61,18 +61,20 @@ bool config_supported(unsigned long long n, int key_words, int payload_bytes, in
         case 256: c = {256, 1}; break;
         case 1024: c = {256, 4}; break;
         case 4096: c = {512, 8}; break;
-        case 8192: c = {512, 16}; break;
+        case 8192: c = payload_bytes == 16 ? KernelConfig{1024, 8} : KernelConfig{512, 16}; break;
         case 16384: c = {1024, 16}; break;
         case 32768: c = {1024, 32}; break;
         default: return false;
     }
-    // tuning aid: MRS_TILE_SHAPE=threads,kpt overrides the shape of 32-bit-key plans with small payloads
+    // tuning aid: MRS_TILE_SHAPE=threads,kpt overrides the default shape
     if (const char* e = std::getenv("MRS_TILE_SHAPE")) {
         int t = 0, k = 0;
-        if (std::sscanf(e, "%d,%d", &t, &k) == 2 && small_pairs && tile_items == 0) c = {t, k};
+        if (std::sscanf(e, "%d,%d", &t, &k) == 2 && tile_items == 0) c = {t, k};
     }
-    if (c.threads * c.kpt >= 4096 && payload_bytes == 16) return false;
-    if (c.threads * c.kpt >= 8192 && !small_pairs) return false;
+    // what the kernel table holds (mrs_radix_dispatch.hpp)
+    const int tile = c.threads * c.kpt;
+    if (payload_bytes == 16 && tile > 8192) return false;
+    if (payload_bytes != 16 && !small_pairs && tile > 4096 && !(c.threads == 1024 && c.kpt == 16)) return false;
     if (cfg) *cfg = c;
     return true;
 }

@@ -11,8 +11,9 @@ namespace mrs {
 // (threads, keys per thread) shapes every key/payload combination supports:
 //   256 x 1  -- the reference's one-key-per-thread 256-key block
 //   256 x 4  -- small tiles (16-byte payloads, small inputs)
-// payloads of at most 4 bytes add 512 x 8, and 32-bit keys with such payloads the large
-// tiles 512 x 16 ... 1024 x 32.  RANK selects how keys are ranked inside a wave
+//   512 x 8
+// 16-byte payloads add 1024 x 8, 64-bit keys with payloads of at most 4 bytes 1024 x 16, and
+// 32-bit keys with such payloads the large tiles 512 x 16 ... 1024 x 32.  RANK selects how keys are ranked inside a wave
 // (kRankMatch / kRankAtomic, see mrs_radix_pass.hpp); each value is compiled in a
 // translation unit of its own.
 template <int MODE, int RANK, bool MAP, int BITS, typename KeyT, typename ValT>
@@ -22,8 +23,14 @@ int launch_pass_shape(int threads, int kpt, const PassArgs& a, hipStream_t s)
     if (threads == T && kpt == K) return launch_pass_cfg<MODE, RANK, MAP, BITS, T, K, KeyT, ValT>(a, s)
     MRS_SHAPE(256, 1);
     MRS_SHAPE(256, 4);
+    MRS_SHAPE(512, 8);
+    if constexpr (sizeof(ValT) > 4) {
+        MRS_SHAPE(1024, 8);
+    }
+    if constexpr (sizeof(ValT) <= 4 && sizeof(KeyT) == 8) {
+        MRS_SHAPE(1024, 16);
+    }
     if constexpr (sizeof(ValT) <= 4) {
-        MRS_SHAPE(512, 8);
         if constexpr (sizeof(KeyT) == 4) {
             MRS_SHAPE(512, 16);
             MRS_SHAPE(512, 32);
