@@ -68,8 +68,9 @@ typedef struct mrs_plan_desc {
     int32_t end_bit;       /* one past the last key bit (32*key_words = NUM_PASSES*8 bits)  */
     int32_t algo;          /* MRS_ALGO_*                                                    */
     int32_t tile_items;    /* keys per workgroup: 0 = default chosen from n and the element
-                              sizes, or 256, 1024, 4096 (payload <= 4 bytes), 8192, 16384,
-                              32768 (u32 keys with payload <= 4 bytes).  256 with
+                              sizes, or 256, 1024, 4096, 8192 (u32 keys with payload <= 4
+                              bytes, or 16-byte payload), 16384 (payload <= 4 bytes), 32768
+                              (u32 keys with payload <= 4 bytes).  256 with
                               MRS_ALGO_THREE_KERNEL gives the reference's histogram
                               layout [256][ceil(n/256)] exactly                             */
 } mrs_plan_desc;
