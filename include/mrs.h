@@ -95,6 +95,14 @@ int mrs_version(void);
 /* ---- context: replaces Instance/adapter/device acquisition, src/main.rs:692-707 */
 int mrs_context_create(int device_id, mrs_context** out);
 int mrs_context_destroy(mrs_context* ctx);
+/* What the context found on its device (the counterpart of reading adapter info and
+ * limits, src/main.rs:697-707).  attribute: MRS_ATTR_*. */
+#define MRS_ATTR_COMPUTE_UNITS 0 /* compute units of the device                               */
+#define MRS_ATTR_RANK_MODE 1     /* how digit passes rank keys inside a wave: 0 = ballot
+                                    matching, 1 = returning LDS atomics (chosen by a device
+                                    check at creation; MRS_RANK=match in the environment
+                                    selects 0)                                                  */
+int mrs_context_get_attribute(const mrs_context* ctx, int attribute, int64_t* value);
 
 /* ---- plan: replaces create_all_buffers' temporaries (histogram + prefix_sums,
  * src/main.rs:45-51,236-253) and the per-pass uniform buffers (src/main.rs:361-374) */

@@ -62,6 +62,20 @@ class Context:
         _lib.check(self.lib.mrs_context_create(self.device.index, ctypes.byref(handle)))
         self._h = handle
 
+    ATTR_COMPUTE_UNITS = 0
+    ATTR_RANK_MODE = 1
+
+    def attribute(self, which):
+        """`mrs_context_get_attribute`: what the context found on its device."""
+        value = ctypes.c_int64()
+        _lib.check(self.lib.mrs_context_get_attribute(self._h, int(which), ctypes.byref(value)))
+        return int(value.value)
+
+    @property
+    def rank_mode(self):
+        """"atomic" (returning LDS atomics) or "match" (ballot matching)."""
+        return "atomic" if self.attribute(self.ATTR_RANK_MODE) == 1 else "match"
+
     def close(self):
         if self._h:
             self.lib.mrs_context_destroy(self._h)

@@ -230,6 +230,17 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
     return MRS_OK;
 }
 
+extern "C" int mrs_context_get_attribute(const mrs_context* ctx, int attribute, int64_t* value)
+{
+    clear_error();
+    if (!ctx || !value) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_get_attribute: null argument");
+    switch (attribute) {
+        case MRS_ATTR_COMPUTE_UNITS: *value = ctx->num_cus; return MRS_OK;
+        case MRS_ATTR_RANK_MODE: *value = ctx->lds_atomics_in_lane_order ? 1 : 0; return MRS_OK;
+        default: return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_get_attribute: unknown attribute %d", attribute);
+    }
+}
+
 extern "C" int mrs_context_destroy(mrs_context* ctx)
 {
     clear_error();
@@ -293,6 +304,8 @@ extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_pla
         const unsigned long long elem_bytes =
             std::max<unsigned long long>(4ull * d->key_words, static_cast<unsigned long long>(d->payload_bytes));
         p->status_word_bytes = (d->n < (1ull << 30) && d->n * elem_bytes <= (1ull << 32)) ? 4 : 8;
+        // test aid: the 64-bit instantiation on inputs small enough to check element by element
+        if (std::getenv("MRS_FORCE_WIDE_STATUS")) p->status_word_bytes = 8;
         const size_t status_bytes =
             align_up(p->histogram_len * p->status_word_bytes * static_cast<size_t>(p->num_passes), 256);
         bytes = 256 + kControlBytes + status_bytes;
