@@ -35,7 +35,7 @@ def check_sorted_pairs(keys_out, idx_out, keys_in):
 
 @pytest.mark.parametrize("log2n,algo_name,bits", [(28, "onesweep", 8), (28, "three_kernel", 8), (30, "onesweep", 8)])
 def test_full_size_sort_properties(ctx, mrs, log2n, algo_name, bits):
-    """BASELINE configs 2 and 3: 2^28 and 2^30 (Morton key, index) pairs on one GPU."""
+    """The metric size and the largest single-GPU size: 2^28 and 2^30 (Morton key, index) pairs."""
     n = 1 << log2n
     free_b, _ = torch.cuda.mem_get_info()
     if free_b < 60 * n:

@@ -274,7 +274,7 @@ def test_plan_capacity_larger_than_n(ctx, oracle, mrs):
 
 
 def test_config1_2pow20_4bit_three_kernel(ctx, oracle, mrs):
-    """BASELINE config 1: 2^20 u32 Morton keys, 4-bit-digit LSD radix (8 passes)."""
+    """2^20 u32 Morton keys, 4-bit-digit LSD radix (8 passes)."""
     n = 1 << 20
     keys = make_keys(oracle, n, 1, "morton30")
     vals = make_vals(oracle, n, 1)

@@ -114,7 +114,7 @@ def test_partial_bit_range(oracle):
 
 
 def test_config0_64k_points_morton30(oracle):
-    """BASELINE config 0: 64K random 3D points -> 30-bit Morton keys, CPU sort (no GPU)."""
+    """The reference-sized CPU case: 64K random 3D points -> 30-bit Morton keys, CPU sort (no GPU)."""
     n = 1 << 16
     xyz = oracle.gen_points(7, n)
     mn, mx = oracle.minmax3(xyz)
