@@ -215,6 +215,41 @@ def test_match_rank_fallback(oracle, mrs, monkeypatch, tile):
     ctx2.close()
 
 
+@pytest.mark.parametrize("key_words,payload_words", SHAPES)
+@pytest.mark.parametrize("bits", [4, 8])
+def test_small_inputs_both_paths(ctx, oracle, mrs, monkeypatch, key_words, payload_words, bits):
+    """Inputs of at most 4096 elements are sorted by one workgroup in one launch; with
+    MRS_NO_SMALL_SORT they take the general multi-launch path.  Both must agree with the checker,
+    including the side the result lands on."""
+    end = 32 * key_words
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("MRS_NO_SMALL_SORT", "1")
+        for n in (1, 2, 63, 64, 65, 255, 256, 257, 1000, 3000, 4095, 4096):
+            for dist in ("random", "all_equal"):
+                keys = make_keys(oracle, n, key_words, dist, seed=n)
+                vals = make_vals(oracle, n, payload_words)
+                ko, vo, in_b = gpu_sort(ctx, mrs, keys, vals, n, key_words, payload_words, bits, 0, end, mrs.ALGO_ONESWEEP)
+                rk, rv = oracle.stable_sort_pairs(keys, vals, n, key_words, payload_words, 0, end)
+                assert in_b == ((end // bits) % 2 == 1)
+                assert np.array_equal(ko, rk), (general, n, dist)
+                if payload_words:
+                    assert np.array_equal(vo, rv), (general, n, dist)
+
+
+def test_small_sort_bit_ranges(ctx, oracle, mrs):
+    """Odd and even pass counts (result in the second or the first buffer pair), partial last digit."""
+    n = 3000
+    for key_words, payload_words in ((1, 1), (2, 4)):
+        keys = make_keys(oracle, n, key_words, "random")
+        vals = make_vals(oracle, n, payload_words)
+        for begin, end, bits in ((0, 30, 8), (0, 24, 8), (3, 11, 8), (0, 8, 8), (5, 31, 4), (0, 12, 4)):
+            ko, vo, in_b = gpu_sort(ctx, mrs, keys, vals, n, key_words, payload_words, bits, begin, end, mrs.ALGO_ONESWEEP)
+            rk, rv = oracle.stable_sort_pairs(keys, vals, n, key_words, payload_words, begin, end)
+            assert in_b == ((-(-(end - begin) // bits)) % 2 == 1)
+            assert np.array_equal(ko, rk) and np.array_equal(vo, rv), (key_words, begin, end, bits)
+
+
 def test_context_attributes(ctx):
     assert ctx.attribute(ctx.ATTR_COMPUTE_UNITS) == 256
     # gfx950 serves the lanes of a returning LDS atomic in lane order; the creation-time check sees it

@@ -38,6 +38,9 @@ int launch_block_histogram_u64(int bits, uint32_t n, const void* keys, uint32_t 
 int launch_global_histogram_u32(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
 int launch_global_histogram_u64(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
 int probe_lds_atomic_order(bool* in_order);
+// mrs_small_sort.hip
+uint32_t small_sort_capacity();
+int launch_small_sort(int key_words, int bits, const SmallSortArgs& a, hipStream_t s);
 
 bool config_supported(unsigned long long n, int key_words, int payload_bytes, int digit_bits, int tile_items, int algo,
                       KernelConfig* cfg)
@@ -408,6 +411,23 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
 
     plan->num_marks = 0;
     if (int rc = mark(plan, "start", s)) return rc;
+    // Small inputs: the whole sort in one launch of one workgroup (MRS_NO_SMALL_SORT=1: A/B aid).
+    if (plan->desc.algo == MRS_ALGO_ONESWEEP && n32 <= small_sort_capacity() && !std::getenv("MRS_NO_SMALL_SORT")) {
+        const bool in_b = (plan->num_passes % 2u) == 1u;
+        SmallSortArgs a{};
+        a.keys_in = keys_a;
+        a.vals_in = vals_a;
+        a.keys_out = in_b ? keys_b : keys_a;
+        a.vals_out = vals_b;
+        a.vals_final = in_b ? nullptr : vals_a;
+        a.n = n32;
+        a.begin_bit = plan->desc.begin_bit;
+        a.end_bit = plan->desc.end_bit;
+        a.num_passes = plan->num_passes;
+        a.payload_bytes = plan->desc.payload_bytes;
+        if (int rc = launch_small_sort(plan->desc.key_words, plan->radix_bits, a, s)) return rc;
+        return mark(plan, "small_sort", s);
+    }
     if (plan->desc.algo == MRS_ALGO_ONESWEEP) {
         const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
         const size_t zero = kControlBytes + align_up(region * plan->num_passes, 256);

@@ -72,6 +72,19 @@ struct OnesweepControl {
 };
 static_assert(sizeof(OnesweepControl) % 16 == 0, "memset block must be a multiple of 16 bytes");
 
+// Arguments of the one-workgroup sort of small inputs (mrs_small_sort.hip).
+struct SmallSortArgs {
+    const void* keys_in;
+    const void* vals_in;
+    void* keys_out;     // where the sorted keys go
+    void* vals_out;     // where the gathered payload goes; never the buffer of vals_in
+    void* vals_final;   // if not null: vals_out is copied here afterwards (may be the buffer of vals_in)
+    uint32_t n;
+    uint32_t begin_bit, end_bit;
+    uint32_t num_passes;
+    uint32_t payload_bytes;  // 0, 4 or 16
+};
+
 struct KernelConfig {
     int threads;
     int kpt;  // keys per thread
