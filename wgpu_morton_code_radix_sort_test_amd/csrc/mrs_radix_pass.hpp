@@ -36,7 +36,8 @@ enum PassMode { kModeScatter = 0, kModeOnesweep = 1 };
 //   kRankMatch : every lane finds the lanes holding its digit with one ballot per digit bit;
 //                the first of them advances the wave's counter in LDS.  About 45 vector
 //                instructions per key for 8-bit digits.
-//   kRankAtomic: one returning LDS atomic add per key on the wave's counter.  The order in
+//   kRankAtomic: one returning LDS atomic add per key on the wave's counter (none when the
+//                whole wave holds one digit).  The order in
 //                which the lanes of one instruction that hit the same counter are served is
 //                not part of the ISA contract; on gfx950 it is ascending lane order, which
 //                is what stability needs.  The host verifies that on the device at context
@@ -313,7 +314,16 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
         const bool mine = FULL || (my_first + i * 64 < tile_valid);
         if constexpr (RANK == kRankAtomic) {
             uint32_t r = 0;
-            if (mine) r = atomicAdd(&sh.wave_hist[wave][d], 1u);
+            // 64 lanes on one counter would be served one after the other (constant digits:
+            // equal keys, zero high bytes, a one-part partition); that case needs no atomic
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+            if (FULL && __builtin_amdgcn_uicmp(d, d0, 32 /* == */) == ~0ull) {
+                r = sh.wave_hist[wave][d0] + lane;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 63) sh.wave_hist[wave][d0] = r + 1;
+            } else if (mine) {
+                r = atomicAdd(&sh.wave_hist[wave][d], 1u);
+            }
             pos.set_fresh(i, r);
         } else {
             // the lowest lane of each digit group advances the counter
