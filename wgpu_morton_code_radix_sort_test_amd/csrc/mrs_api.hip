@@ -58,8 +58,9 @@ bool config_supported(unsigned long long n, int key_words, int payload_bytes, in
             if (payload_bytes == 16) c = n >= (1ull << 23) ? KernelConfig{1024, 8} : (n >= (1ull << 20) ? KernelConfig{512, 8} : KernelConfig{256, 4});
             else if (key_words == 2) c = n >= (1ull << 24) ? KernelConfig{1024, 16} : KernelConfig{512, 8};
             else if (n >= (1ull << 25)) c = {1024, 32};
-            else if (n >= (1ull << 24)) c = {1024, 16};
-            else c = {512, 16};
+            else if (n >= (1ull << 20)) c = {1024, 16};
+            else if (n >= (1ull << 17)) c = {512, 16};
+            else c = {512, 8};
             break;
         case 256: c = {256, 1}; break;
         case 1024: c = {256, 4}; break;
@@ -126,8 +127,11 @@ static int launch_block_hist(const mrs_plan* p, uint32_t n, const void* keys, ui
 static int launch_global_hist(const mrs_plan* p, const GlobalHistArgs& a, hipStream_t s)
 {
     const uint64_t vec = p->desc.key_words == 1 ? 4 : 2;
-    uint64_t blocks = (a.n / vec + 255) / 256;
-    const uint64_t cap = static_cast<uint64_t>(p->ctx->num_cus) * 16;
+    // Every workgroup ends with up to passes x radix atomic adds on the same global words, so
+    // each gets at least 8 vectors per thread to amortise them (MRS_HIST_BLOCKS_PER_CU: tuning aid).
+    static const uint64_t per_cu = std::getenv("MRS_HIST_BLOCKS_PER_CU") ? std::atoi(std::getenv("MRS_HIST_BLOCKS_PER_CU")) : 16;
+    uint64_t blocks = (a.n / vec + 256 * 8 - 1) / (256 * 8);
+    const uint64_t cap = static_cast<uint64_t>(p->ctx->num_cus) * per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     if (p->desc.key_words == 1) return launch_global_histogram_u32(p->radix_bits, static_cast<int>(blocks), a, s);
@@ -475,7 +479,6 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
             a.digit_base = plan->control->ghist + static_cast<size_t>(pass) * plan->radix;
             a.status = plan->status + static_cast<size_t>(pass) * num_tiles * plan->radix * plan->status_word_bytes;
             a.wide_status = plan->status_word_bytes == 8;
-            a.use_ticket = 1;
             a.tile_counter = &plan->control->tile_counter[pass];
             a.error_flag = plan->error_flag;
 #ifdef MRS_STAMPS
@@ -660,7 +663,6 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
     a.digit_base = plan->control->ghist;
     a.status = plan->status;
     a.wide_status = plan->status_word_bytes == 8;
-    a.use_ticket = 1;
     a.tile_counter = &plan->control->tile_counter[0];
     a.error_flag = plan->error_flag;
     return launch_pass(plan, kModeOnesweep, a, s);

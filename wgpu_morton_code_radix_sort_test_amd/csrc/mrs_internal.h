@@ -56,8 +56,6 @@ struct PassArgs {
     uint32_t wide_status;        // status words are 64-bit (inputs of 2^30 elements and more)
     uint32_t* tile_counter;      // ticket dispenser of this pass
     uint32_t* error_flag;
-    uint32_t first_tile;         // index of the tile of workgroup 0
-    uint32_t use_ticket;         // onesweep: tile ids come from the ticket counter
     uint32_t atomic_rank;        // host side only: rank with returning LDS atomics (kRankAtomic)
 #ifdef MRS_STAMPS
     unsigned long long* stamps;  // diagnostic builds only: [num_tiles][8] phase clocks

@@ -569,13 +569,13 @@ __global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) voi
     // a workgroup that is already running.
     if (MODE == kModeOnesweep) {
         if (tid == 0) {
-            sh.tile = a.use_ticket ? atomicAdd(a.tile_counter, 1u) : blockIdx.x;
+            sh.tile = atomicAdd(a.tile_counter, 1u);
             sh.abort = 0;
         }
     }
     for (int j = tid; j < S::WAVES * S::RADIX; j += THREADS) (&sh.wave_hist[0][0])[j] = 0;
     __syncthreads();
-    const uint32_t tile = a.first_tile + (MODE == kModeOnesweep ? sh.tile : blockIdx.x);
+    const uint32_t tile = MODE == kModeOnesweep ? sh.tile : blockIdx.x;
 #ifdef MRS_STAMPS
     if (a.stamps && tid == 0) a.stamps[static_cast<size_t>(tile) * 16 + 0] = t_begin;
 #endif
