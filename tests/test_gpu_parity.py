@@ -250,6 +250,36 @@ def test_small_sort_bit_ranges(ctx, oracle, mrs):
             assert np.array_equal(ko, rk) and np.array_equal(vo, rv), (key_words, begin, end, bits)
 
 
+def test_sort_fuzz(ctx, oracle, mrs):
+    """Seeded random plans: size, element type, digit width, bit range, tile size, algorithm and
+    key distribution drawn together; every result must equal the checker's stable sort."""
+    rng = np.random.RandomState(20240611)
+    tiles_small = {(1, 0): [0, 256, 1024, 4096, 8192, 16384, 32768], (1, 1): [0, 256, 1024, 4096, 8192, 16384, 32768],
+                   (2, 0): [0, 256, 1024, 4096, 16384], (2, 1): [0, 256, 1024, 4096, 16384],
+                   (2, 4): [0, 256, 1024, 4096, 8192], (1, 4): [0, 256, 1024, 4096, 8192]}
+    for case in range(60):
+        key_words, payload_words = [(1, 0), (1, 1), (2, 0), (2, 1), (2, 4), (1, 4)][rng.randint(6)]
+        bits = int(rng.choice([4, 8]))
+        key_bits = 32 * key_words
+        begin = int(rng.randint(0, key_bits - 1))
+        end = int(rng.randint(begin + 1, key_bits + 1))
+        if (end - begin + bits - 1) // bits > 16:
+            end = begin + 16 * bits
+        tile = int(rng.choice(tiles_small[(key_words, payload_words)]))
+        n = int(rng.choice([rng.randint(1, 70), rng.randint(70, 5000), rng.randint(5000, 120000), rng.randint(120000, 400000)]))
+        dist = DISTRIBUTIONS[rng.randint(len(DISTRIBUTIONS))]
+        algo = mrs.ALGO_ONESWEEP if rng.randint(3) else mrs.ALGO_THREE_KERNEL
+        keys = make_keys(oracle, n, key_words, dist, seed=case)
+        vals = make_vals(oracle, n, payload_words)
+        ko, vo, in_b = gpu_sort(ctx, mrs, keys, vals, n, key_words, payload_words, bits, begin, end, algo, tile_items=tile)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, key_words, payload_words, begin, end)
+        what = (case, key_words, payload_words, bits, begin, end, tile, n, dist, algo)
+        assert in_b == (((end - begin + bits - 1) // bits) % 2 == 1), what
+        assert np.array_equal(ko, rk), what
+        if payload_words:
+            assert np.array_equal(vo, rv), what
+
+
 def test_context_attributes(ctx):
     assert ctx.attribute(ctx.ATTR_COMPUTE_UNITS) == 256
     # gfx950 serves the lanes of a returning LDS atomic in lane order; the creation-time check sees it
