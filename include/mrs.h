@@ -102,6 +102,9 @@ int mrs_context_destroy(mrs_context* ctx);
                                     matching, 1 = returning LDS atomics (chosen by a device
                                     check at creation; MRS_RANK=match in the environment
                                     selects 0)                                                  */
+#define MRS_ATTR_DIE_AWARE_TICKETS 2 /* 1 if a large grid was seen to land on all 8 dies (XCDs) in
+                                    comparable shares: onesweep passes then hand blocks of
+                                    consecutive tiles to workgroups of one die               */
 int mrs_context_get_attribute(const mrs_context* ctx, int attribute, int64_t* value);
 
 /* ---- plan: replaces create_all_buffers' temporaries (histogram + prefix_sums,

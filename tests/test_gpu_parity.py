@@ -284,6 +284,8 @@ def test_context_attributes(ctx):
     assert ctx.attribute(ctx.ATTR_COMPUTE_UNITS) == 256
     # gfx950 serves the lanes of a returning LDS atomic in lane order; the creation-time check sees it
     assert ctx.rank_mode == "atomic"
+    # all 8 dies of an MI355X in its default partition mode receive workgroups
+    assert ctx.attribute(ctx.ATTR_DIE_AWARE_TICKETS) == 1
 
 
 def test_sort_large_tile_u64_keys(ctx, oracle, mrs):

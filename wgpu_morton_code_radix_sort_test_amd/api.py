@@ -64,6 +64,7 @@ class Context:
 
     ATTR_COMPUTE_UNITS = 0
     ATTR_RANK_MODE = 1
+    ATTR_DIE_AWARE_TICKETS = 2
 
     def attribute(self, which):
         """`mrs_context_get_attribute`: what the context found on its device."""

@@ -38,6 +38,7 @@ int launch_block_histogram_u64(int bits, uint32_t n, const void* keys, uint32_t 
 int launch_global_histogram_u32(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
 int launch_global_histogram_u64(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
 int probe_lds_atomic_order(bool* in_order);
+int probe_die_ids(bool* all_dies);
 // mrs_small_sort.hip
 uint32_t small_sort_capacity();
 int launch_small_sort(int key_words, int bits, const SmallSortArgs& a, hipStream_t s);
@@ -103,6 +104,17 @@ static uint32_t pass_mask(const mrs_plan* p, uint32_t pass)
     const uint32_t shift = pass_shift(p, pass);
     const uint32_t width = p->desc.end_bit - shift < p->radix_bits ? p->desc.end_bit - shift : p->radix_bits;
     return (1u << width) - 1u;
+}
+
+// Consecutive tiles are handed to workgroups of the same die in blocks of this many, so that the
+// output lines two neighbouring tiles share meet in one L2 (8 % of the pass time at 2^28 pairs).
+// Blocks must stay well below the tiles a die has in flight (32 with one workgroup per compute
+// unit), or the dies wait for each other.  0 = a single ticket list; MRS_XCD_BLOCK: tuning aid.
+static uint32_t xcd_block_tiles(const mrs_context* ctx)
+{
+    static const int env = std::getenv("MRS_XCD_BLOCK") ? std::atoi(std::getenv("MRS_XCD_BLOCK")) : -1;
+    if (!ctx->workgroups_on_all_dies) return 0;
+    return env >= 0 ? static_cast<uint32_t>(env) : 8u;
 }
 
 static int launch_pass(const mrs_plan* p, int mode, const PassArgs& args, hipStream_t s)
@@ -219,13 +231,15 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
         return fail(MRS_ERR_UNSUPPORTED, "mrs_context_create: device %d is %s; this library is built for gfx950 only",
                     device_id, prop.gcnArchName);
     // Which ranking the digit passes use on this device (MRS_RANK=match skips the faster one).
-    bool in_order = false;
+    bool in_order = false, all_dies = false;
     const char* rank_env = std::getenv("MRS_RANK");
-    if (!(rank_env && std::strcmp(rank_env, "match") == 0)) {
+    {
         int prev = -1;
         MRS_HIP_TRY(hipGetDevice(&prev));
         MRS_HIP_TRY(hipSetDevice(device_id));
-        const int rc = probe_lds_atomic_order(&in_order);
+        int rc = MRS_OK;
+        if (!(rank_env && std::strcmp(rank_env, "match") == 0)) rc = probe_lds_atomic_order(&in_order);
+        if (rc == MRS_OK && prop.multiProcessorCount == 256) rc = probe_die_ids(&all_dies);
         MRS_HIP_TRY(hipSetDevice(prev));
         if (rc) return rc;
     }
@@ -233,6 +247,7 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount;
     c->lds_atomics_in_lane_order = in_order;
+    c->workgroups_on_all_dies = all_dies;
     *out = c;
     return MRS_OK;
 }
@@ -244,6 +259,7 @@ extern "C" int mrs_context_get_attribute(const mrs_context* ctx, int attribute, 
     switch (attribute) {
         case MRS_ATTR_COMPUTE_UNITS: *value = ctx->num_cus; return MRS_OK;
         case MRS_ATTR_RANK_MODE: *value = ctx->lds_atomics_in_lane_order ? 1 : 0; return MRS_OK;
+        case MRS_ATTR_DIE_AWARE_TICKETS: *value = ctx->workgroups_on_all_dies ? 1 : 0; return MRS_OK;
         default: return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_get_attribute: unknown attribute %d", attribute);
     }
 }
@@ -479,7 +495,8 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
             a.digit_base = plan->control->ghist + static_cast<size_t>(pass) * plan->radix;
             a.status = plan->status + static_cast<size_t>(pass) * num_tiles * plan->radix * plan->status_word_bytes;
             a.wide_status = plan->status_word_bytes == 8;
-            a.tile_counter = &plan->control->tile_counter[pass];
+            a.tile_counter = plan->control->tile_counter[pass];
+            a.xcd_block = xcd_block_tiles(plan->ctx);
             a.error_flag = plan->error_flag;
 #ifdef MRS_STAMPS
             static const uint32_t stamp_pass = std::getenv("MRS_STAMP_PASS") ? std::atoi(std::getenv("MRS_STAMP_PASS")) : 1;
@@ -663,7 +680,8 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
     a.digit_base = plan->control->ghist;
     a.status = plan->status;
     a.wide_status = plan->status_word_bytes == 8;
-    a.tile_counter = &plan->control->tile_counter[0];
+    a.tile_counter = plan->control->tile_counter[0];
+    a.xcd_block = xcd_block_tiles(plan->ctx);
     a.error_flag = plan->error_flag;
     return launch_pass(plan, kModeOnesweep, a, s);
 }

@@ -36,6 +36,7 @@ void clear_error();
 
 constexpr int kMaxPasses = 16;   // 64-bit keys with 4-bit digits
 constexpr int kMaxRadix = 256;
+constexpr int kTicketLists = 8;  // one per accelerator die (XCD) of the MI355X
 
 // Per-launch arguments of a digit pass.
 struct PassArgs {
@@ -54,7 +55,8 @@ struct PassArgs {
     const uint32_t* digit_base;  // exclusive scan of the global digit histogram of this pass
     void* status;                // [num_tiles][radix] tile status words of this pass, zeroed
     uint32_t wide_status;        // status words are 64-bit (inputs of 2^30 elements and more)
-    uint32_t* tile_counter;      // ticket dispenser of this pass
+    uint32_t* tile_counter;      // ticket dispensers of this pass: kTicketLists counters
+    uint32_t xcd_block;          // tiles per ticket block (see draw_tile in mrs_radix_pass.hpp); 0 = one list
     uint32_t* error_flag;
     uint32_t atomic_rank;        // host side only: rank with returning LDS atomics (kRankAtomic)
 #ifdef MRS_STAMPS
@@ -66,7 +68,7 @@ struct PassArgs {
 // one memset per sort call together with the status words that follow it.
 struct OnesweepControl {
     uint32_t ghist[kMaxPasses * kMaxRadix];  // global digit histograms, then their scans
-    uint32_t tile_counter[kMaxPasses];
+    uint32_t tile_counter[kMaxPasses][kTicketLists];
 };
 static_assert(sizeof(OnesweepControl) % 16 == 0, "memset block must be a multiple of 16 bytes");
 
@@ -97,6 +99,9 @@ struct mrs_context {
     // ascending lane order on this device (checked at creation): the digit passes may rank
     // with them.
     bool lds_atomics_in_lane_order;
+    // A large grid lands on all 8 dies in comparable shares (checked at creation): the digit
+    // passes may hand consecutive tiles to workgroups of one die.
+    bool workgroups_on_all_dies;
 };
 
 struct mrs_plan {

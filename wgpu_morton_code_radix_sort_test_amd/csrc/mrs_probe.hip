@@ -53,7 +53,42 @@ __global__ __launch_bounds__(kProbeThreads) void lds_atomic_order_probe_kernel(u
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// Which die (XCD) does a workgroup run on?  The die-aware ticket lists of the digit pass need
+// workgroups on every one of the 8 dies; the probe counts what a large grid reads.
+__global__ void die_id_probe_kernel(uint32_t* hist)
+{
+    if (threadIdx.x == 0) {
+        const uint32_t die = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));  // HW_REG_XCC_ID[3:0]
+        atomicAdd(&hist[die & 15u], 1u);
+    }
+}
+
 }  // namespace
+
+// *all_dies = a grid of many workgroups lands on dies 0..7 in comparable shares and on no other id.
+int probe_die_ids(bool* all_dies)
+{
+    *all_dies = false;
+    constexpr uint32_t kGrid = 8192;
+    uint32_t* d_hist = nullptr;
+    MRS_HIP_TRY(hipMalloc(&d_hist, 16 * sizeof(uint32_t)));
+    hipError_t e = hipMemset(d_hist, 0, 16 * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(die_id_probe_kernel, dim3(kGrid), dim3(64), 0, 0, d_hist);
+        e = hipGetLastError();
+    }
+    uint32_t hist[16] = {};
+    if (e == hipSuccess) e = hipMemcpy(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost);
+    (void)hipFree(d_hist);
+    if (e != hipSuccess) return fail(MRS_ERR_HIP, "die id probe failed: %s", hipGetErrorString(e));
+    bool ok = true;
+    for (int i = 0; i < 16; ++i) {
+        if (i < kTicketLists) ok = ok && hist[i] >= kGrid / kTicketLists / 2;
+        else ok = ok && hist[i] == 0;
+    }
+    *all_dies = ok;
+    return MRS_OK;
+}
 
 // *in_order = the device passed; the current device must be the one to test.
 int probe_lds_atomic_order(bool* in_order)

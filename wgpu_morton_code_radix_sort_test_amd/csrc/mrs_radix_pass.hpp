@@ -548,6 +548,38 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
 #endif
 }
 
+// Tile id of a workgroup.  With xcd_block = B > 0 the tiles are dealt in blocks of B
+// consecutive tiles, block g to die g % 8: a workgroup draws from the list of the die it runs
+// on (hardware register XCC_ID), and from the other lists once its own is exhausted.  Every
+// list is drawn in ascending order and there are exactly as many workgroups as tiles, so the
+// lowest unfinished tile is always held by a running workgroup or is the next to be drawn:
+// the look-back cannot starve, whatever the die id reads.
+__device__ __forceinline__ uint32_t draw_tile(const PassArgs& a)
+{
+    const uint32_t B = a.xcd_block;
+    if (B == 0) return atomicAdd(a.tile_counter, 1u);
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
+    const uint32_t die = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (kTicketLists - 1);
+    for (uint32_t i = 0; i < kTicketLists; ++i) {
+        const uint32_t list = (die + i) & (kTicketLists - 1);
+        const uint32_t k = atomicAdd(a.tile_counter + list, 1u);
+        const unsigned long long tile = (static_cast<unsigned long long>(k / B) * kTicketLists + list) * B + k % B;
+        if (tile < a.num_tiles) return static_cast<uint32_t>(tile);
+    }
+    return a.num_tiles;  // not reached: as many workgroups as tiles
+}
+
+// The scatter of the three-kernel pass has no chain, so any one-to-one map from workgroup to
+// tile will do.  Workgroups are dealt to the 8 dies round robin by index; this map gives the 8
+// workgroups that land on one die out of every 64 a block of 8 consecutive tiles, for the same
+// reason as the ticket lists above.  The last incomplete group of 64 keeps the identity.
+__device__ __forceinline__ uint32_t die_local_tile(uint32_t wg, uint32_t num_tiles)
+{
+    if (wg >= (num_tiles & ~63u)) return wg;
+    const uint32_t r = wg & 63u;
+    return (wg & ~63u) + (r & 7u) * 8u + (r >> 3);
+}
+
 // Waves per SIMD the register allocation must leave room for.  A 512 x 32 tile holds
 // 64 KiB in LDS, so two workgroups fit a compute unit only if each wave stays within
 // 128 registers; the other shapes are left to the compiler.
@@ -569,13 +601,14 @@ __global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) voi
     // a workgroup that is already running.
     if (MODE == kModeOnesweep) {
         if (tid == 0) {
-            sh.tile = atomicAdd(a.tile_counter, 1u);
+            sh.tile = draw_tile(a);
             sh.abort = 0;
         }
     }
     for (int j = tid; j < S::WAVES * S::RADIX; j += THREADS) (&sh.wave_hist[0][0])[j] = 0;
     __syncthreads();
-    const uint32_t tile = MODE == kModeOnesweep ? sh.tile : blockIdx.x;
+    const uint32_t tile = MODE == kModeOnesweep ? sh.tile : die_local_tile(blockIdx.x, a.num_tiles);
+    if (tile >= a.num_tiles) return;  // uniform; cannot happen with one workgroup per tile
 #ifdef MRS_STAMPS
     if (a.stamps && tid == 0) a.stamps[static_cast<size_t>(tile) * 16 + 0] = t_begin;
 #endif
