@@ -106,6 +106,12 @@ int mrs_context_destroy(mrs_context* ctx);
                                     comparable shares: onesweep passes then hand blocks of
                                     consecutive tiles to workgroups of one die               */
 int mrs_context_get_attribute(const mrs_context* ctx, int attribute, int64_t* value);
+/* MRS_ATTR_DIE_AWARE_TICKETS can be cleared (value 0) and, where the creation-time check passed,
+ * set again.  Clear it when several sorts run concurrently on one device: with die-aware tickets
+ * a pass makes progress only if it keeps getting workgroup slots on every die, which a second
+ * long-running kernel can deny it (the pass then ends in MRS_ERR_DEVICE_TIMEOUT after 4 s instead
+ * of completing).  Sorts that follow each other on one stream, the normal case, are not affected. */
+int mrs_context_set_attribute(mrs_context* ctx, int attribute, int64_t value);
 
 /* ---- plan: replaces create_all_buffers' temporaries (histogram + prefix_sums,
  * src/main.rs:45-51,236-253) and the per-pass uniform buffers (src/main.rs:361-374) */

@@ -49,6 +49,7 @@ extern "C" {
     pub fn mrs_context_create(device_id: c_int, out: *mut *mut mrs_context) -> c_int;
     pub fn mrs_context_destroy(ctx: *mut mrs_context) -> c_int;
     pub fn mrs_context_get_attribute(ctx: *const mrs_context, attribute: c_int, value: *mut i64) -> c_int;
+    pub fn mrs_context_set_attribute(ctx: *mut mrs_context, attribute: c_int, value: i64) -> c_int;
     pub fn mrs_plan_create(ctx: *mut mrs_context, desc: *const PlanDesc, out: *mut *mut mrs_plan) -> c_int;
     pub fn mrs_plan_destroy(plan: *mut mrs_plan) -> c_int;
     pub fn mrs_plan_get_info(plan: *const mrs_plan, info: *mut PlanInfo) -> c_int;

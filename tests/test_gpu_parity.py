@@ -288,6 +288,25 @@ def test_context_attributes(ctx):
     assert ctx.attribute(ctx.ATTR_DIE_AWARE_TICKETS) == 1
 
 
+def test_single_ticket_list(oracle, mrs):
+    """Die-aware tickets switched off through the C ABI: one ticket list, same results."""
+    ctx2 = mrs.Context(0)
+    ctx2.set_attribute(ctx2.ATTR_DIE_AWARE_TICKETS, 0)
+    assert ctx2.attribute(ctx2.ATTR_DIE_AWARE_TICKETS) == 0
+    with pytest.raises(mrs.MrsError):
+        ctx2.set_attribute(ctx2.ATTR_RANK_MODE, 0)
+    n = 300007
+    keys = make_keys(oracle, n, 1, "morton30")
+    vals = make_vals(oracle, n, 1)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+    for tile in (256, 8192):
+        ko, vo, _ = gpu_sort(ctx2, mrs, keys, vals, n, 1, 1, 8, 0, 32, mrs.ALGO_ONESWEEP, tile_items=tile)
+        assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+    ctx2.set_attribute(ctx2.ATTR_DIE_AWARE_TICKETS, 1)
+    assert ctx2.attribute(ctx2.ATTR_DIE_AWARE_TICKETS) == 1
+    ctx2.close()
+
+
 def test_sort_large_tile_u64_keys(ctx, oracle, mrs):
     """64-bit keys with a 4-byte payload on the 16384-element tile."""
     n = 7 * 16384 + 3

@@ -64,6 +64,7 @@ SIGNATURES = {
     "mrs_context_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "mrs_context_destroy": (ctypes.c_int, [_vp]),
     "mrs_context_get_attribute": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
+    "mrs_context_set_attribute": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64]),
     "mrs_plan_create": (ctypes.c_int, [_vp, ctypes.POINTER(PlanDesc), ctypes.POINTER(_vp)]),
     "mrs_plan_destroy": (ctypes.c_int, [_vp]),
     "mrs_plan_get_info": (ctypes.c_int, [_vp, ctypes.POINTER(PlanInfoStruct)]),

@@ -72,6 +72,10 @@ class Context:
         _lib.check(self.lib.mrs_context_get_attribute(self._h, int(which), ctypes.byref(value)))
         return int(value.value)
 
+    def set_attribute(self, which, value):
+        """`mrs_context_set_attribute` (ATTR_DIE_AWARE_TICKETS only)."""
+        _lib.check(self.lib.mrs_context_set_attribute(self._h, int(which), int(value)))
+
     @property
     def rank_mode(self):
         """"atomic" (returning LDS atomics) or "match" (ballot matching)."""

@@ -113,7 +113,7 @@ static uint32_t pass_mask(const mrs_plan* p, uint32_t pass)
 static uint32_t xcd_block_tiles(const mrs_context* ctx)
 {
     static const int env = std::getenv("MRS_XCD_BLOCK") ? std::atoi(std::getenv("MRS_XCD_BLOCK")) : -1;
-    if (!ctx->workgroups_on_all_dies) return 0;
+    if (!ctx->die_aware_tickets) return 0;
     return env >= 0 ? static_cast<uint32_t>(env) : 8u;
 }
 
@@ -248,6 +248,7 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
     c->num_cus = prop.multiProcessorCount;
     c->lds_atomics_in_lane_order = in_order;
     c->workgroups_on_all_dies = all_dies;
+    c->die_aware_tickets = all_dies;
     *out = c;
     return MRS_OK;
 }
@@ -259,9 +260,21 @@ extern "C" int mrs_context_get_attribute(const mrs_context* ctx, int attribute, 
     switch (attribute) {
         case MRS_ATTR_COMPUTE_UNITS: *value = ctx->num_cus; return MRS_OK;
         case MRS_ATTR_RANK_MODE: *value = ctx->lds_atomics_in_lane_order ? 1 : 0; return MRS_OK;
-        case MRS_ATTR_DIE_AWARE_TICKETS: *value = ctx->workgroups_on_all_dies ? 1 : 0; return MRS_OK;
+        case MRS_ATTR_DIE_AWARE_TICKETS: *value = ctx->die_aware_tickets ? 1 : 0; return MRS_OK;
         default: return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_get_attribute: unknown attribute %d", attribute);
     }
+}
+
+extern "C" int mrs_context_set_attribute(mrs_context* ctx, int attribute, int64_t value)
+{
+    clear_error();
+    if (!ctx) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_set_attribute: null context");
+    if (attribute != MRS_ATTR_DIE_AWARE_TICKETS)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_set_attribute: attribute %d cannot be set", attribute);
+    if (value != 0 && !ctx->workgroups_on_all_dies)
+        return fail(MRS_ERR_UNSUPPORTED, "mrs_context_set_attribute: workgroups were not seen on all 8 dies of this device");
+    ctx->die_aware_tickets = value != 0;
+    return MRS_OK;
 }
 
 extern "C" int mrs_context_destroy(mrs_context* ctx)

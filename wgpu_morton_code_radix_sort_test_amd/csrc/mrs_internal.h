@@ -102,6 +102,7 @@ struct mrs_context {
     // A large grid lands on all 8 dies in comparable shares (checked at creation): the digit
     // passes may hand consecutive tiles to workgroups of one die.
     bool workgroups_on_all_dies;
+    bool die_aware_tickets;  // workgroups_on_all_dies, unless switched off (mrs_context_set_attribute)
 };
 
 struct mrs_plan {
