@@ -60,6 +60,39 @@ def test_full_size_sort_properties(ctx, mrs, log2n, algo_name, bits):
     plan.close()
 
 
+@pytest.mark.parametrize("payload_words", [1, 4])
+def test_large_u64_keys_properties(ctx, mrs, payload_words):
+    """64-bit keys (the reference's code type) with an index or a 16-byte TriangleIndices-sized
+    payload at 2^26 elements: sorted as u64, stable, payload follows its key."""
+    n = 1 << 26
+    lo = ctx.generate_u32(11, 1, n)
+    hi = ctx.generate_u32(11, 2, n) & 0x3FFFF  # some equal high words, as short codes have
+    keys = torch.stack([lo, hi], dim=1).reshape(-1).contiguous()
+    src = torch.arange(n, dtype=torch.int32, device=ctx.device)
+    if payload_words == 1:
+        vals = src.clone()
+    else:
+        vals = torch.stack([src, src ^ 0x5A5A5A5A, lo, hi], dim=1).reshape(-1).contiguous()
+    k64_in = (hi.to(torch.int64) << 32) | (lo.to(torch.int64) & 0xFFFFFFFF)
+    plan = mrs.SortPlan(ctx, n, key_words=2, payload_bytes=4 * payload_words)
+    kb, vb = torch.empty_like(keys), torch.empty_like(vals)
+    in_b = plan.sort_pairs(keys, vals, kb, vb)
+    plan.check()
+    assert not in_b  # 8 passes
+    ko = keys.view(n, 2)
+    k64 = (ko[:, 1].to(torch.int64) << 32) | (ko[:, 0].to(torch.int64) & 0xFFFFFFFF)
+    vo = vals.view(n, payload_words)
+    origin = vo[:, 0].to(torch.int64)
+    dk = k64[1:] - k64[:-1]
+    assert bool((dk >= 0).all()), "keys are not sorted"
+    assert bool(((dk > 0) | (origin[1:] > origin[:-1])).all()), "equal keys lost their input order"
+    assert bool((k64_in[origin] == k64).all()), "payload does not point at the key's origin"
+    if payload_words == 4:
+        assert bool((vo[:, 1] == (vo[:, 0] ^ 0x5A5A5A5A)).all()) and bool((vo[:, 2] == ko[:, 0]).all()) \
+            and bool((vo[:, 3] == ko[:, 1]).all()), "the 16-byte payload was torn"
+    plan.close()
+
+
 def test_full_size_head_matches_oracle(ctx, mrs, oracle):
     """The first 2^20 outputs of a 2^26 sort equal the oracle's, bit for bit (the oracle sorts
     the whole 2^26 in seconds)."""
