@@ -176,6 +176,18 @@ int mrs_scatter(mrs_plan* plan, uint64_t n, const void* keys_in, const void* val
                 void* keys_out, void* vals_out, const uint32_t* scanned_hist_dev,
                 uint32_t pass, void* stream);
 
+/* Sort by key, moving each wide record once: the variant the reference's own comments
+ * anticipate for TriangleIndices (src/types.rs:26-36, src/shaders/radix_sort_index.wgsl:3-6)
+ * instead of carrying 16 bytes through every pass (radix_sort_index.wgsl:281-307).  `plan` must
+ * have payload_bytes == 4: (key, source index) pairs are sorted exactly as by mrs_sort_pairs, with
+ * index_a filled with 0..n-1 first (index_a, index_b: u32[n] scratch), then
+ * records_out[j] = records_in[index[j]] for records of record_bytes (a positive multiple of 4).
+ * Keys end in keys_a or keys_b as reported by result_in_b; records_out must not alias records_in.
+ * The sorted source indices stay in index_a or index_b (same side as the keys). */
+int mrs_sort_gather(mrs_plan* plan, uint64_t n, void* keys_a, void* keys_b, uint32_t* index_a,
+                    uint32_t* index_b, const void* records_in, void* records_out,
+                    uint32_t record_bytes, void* stream, int* result_in_b);
+
 /* ---- multi-GPU building blocks (sort sharded by top-digit bucket) ---------- */
 /* counts_dev[b] (u64, 1 << bits entries) = number of keys whose bits
  * [shift, shift+bits) equal b.  Input to the all-reduce of the global digit

@@ -280,6 +280,32 @@ def test_sort_fuzz(ctx, oracle, mrs):
             assert np.array_equal(vo, rv), what
 
 
+@pytest.mark.parametrize("key_words", [1, 2])
+@pytest.mark.parametrize("record_words", [1, 2, 3, 4, 9])
+def test_sort_gather_matches_oracle(ctx, oracle, mrs, key_words, record_words):
+    """mrs_sort_gather (sort key + source index, move each record once) gives what carrying the
+    record through every pass gives: the checker's stable sort of (key, record) pairs."""
+    end = 32 * key_words
+    for n in (1, 3000, 4097, 100001):
+        keys = make_keys(oracle, n, key_words, "few_distinct", seed=n)
+        recs = make_vals(oracle, n, record_words)
+        plan = mrs.SortPlan(ctx, n, key_words=key_words, payload_bytes=4)
+        ka = to_dev(keys, ctx.device)
+        kb = torch.full_like(ka, -1)
+        rin = to_dev(recs, ctx.device)
+        rout = torch.full_like(rin, -1)
+        in_b, index = plan.sort_gather(ka, kb, rin, rout, 4 * record_words, n=n)
+        plan.check()
+        assert in_b == ((end // 8) % 2 == 1)
+        rk, rv = oracle.stable_sort_pairs(keys, recs, n, key_words, record_words, 0, end)
+        assert np.array_equal(to_u32(kb if in_b else ka)[: n * key_words], rk)
+        assert np.array_equal(to_u32(rout)[: n * record_words], rv)
+        # the sorted source indices are left behind as well
+        src = to_u32(index)[:n].astype(np.int64)
+        assert np.array_equal(recs.reshape(n, record_words)[src].reshape(-1), rv)
+        plan.close()
+
+
 def test_context_attributes(ctx):
     assert ctx.attribute(ctx.ATTR_COMPUTE_UNITS) == 256
     # gfx950 serves the lanes of a returning LDS atomic in lane order; the creation-time check sees it
@@ -414,6 +440,18 @@ def test_run_headless(ctx, oracle, mrs, algo_name):
     assert in_b == res["buffers"].result_in_2 == False  # noqa: E712  (8 passes: result in the first buffers)
     assert np.array_equal(res["keys"].view(np.uint32), rk)
     assert np.array_equal(res["triangles"], rv.reshape(-1, 4)[:, :3])
+
+
+@pytest.mark.parametrize("num_triangles", [3000, 70001])
+def test_run_headless_gathered_payload(ctx, oracle, mrs, num_triangles):
+    """The same entry point with the TriangleIndices moved once at the end instead of through
+    every pass: identical codes and triangles."""
+    carried = mrs.run_headless(0, num_triangles=num_triangles)
+    gathered = mrs.run_headless(0, num_triangles=num_triangles, gather_payload=True)
+    assert gathered["sorted"] and gathered["times_unsorted"] == 0
+    assert np.array_equal(carried["keys"], gathered["keys"])
+    assert np.array_equal(carried["triangles"], gathered["triangles"])
+    assert gathered["buffers"].triangles_in_2
 
 
 # ---- multi-GPU building blocks ----------------------------------------------------------------------

@@ -25,11 +25,13 @@ def main():
     ap.add_argument("--key-words", type=int, default=1)
     ap.add_argument("--payload-bytes", type=int, default=4)
     ap.add_argument("--dist", default="morton30", choices=["morton30", "random", "sorted", "equal"])
+    ap.add_argument("--gather", action="store_true",
+                    help="sort (key, source index) and move each record of --payload-bytes once (mrs_sort_gather)")
     args = ap.parse_args()
     ctx = mrs.Context(0)
     n = 1 << args.log2n
     algo = mrs.ALGO_ONESWEEP if args.algo == "onesweep" else mrs.ALGO_THREE_KERNEL
-    plan = mrs.SortPlan(ctx, n, key_words=args.key_words, payload_bytes=args.payload_bytes,
+    plan = mrs.SortPlan(ctx, n, key_words=args.key_words, payload_bytes=4 if args.gather else args.payload_bytes,
                         digit_bits=args.digit_bits, algo=algo, tile_items=args.tile_items)
     plan.set_timing(True)
     kw, pw = args.key_words, args.payload_bytes // 4
@@ -52,12 +54,20 @@ def main():
                 keys.fill_(12345)
             idx = torch.arange(n, dtype=torch.int32, device=ctx.device)
         vals = idx if pw == 1 else (ctx.generate_u32(5, it, n * pw) if pw else None)
-        plan.sort_pairs(keys, vals, kb, vb if pw else None)
-        tm = plan.timings()
+        if args.gather:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            plan.sort_gather(keys, kb, vals, vb, args.payload_bytes)
+            e1.record()
+            torch.cuda.synchronize()
+            tm = plan.timings() + [("whole call (events around it)", e0.elapsed_time(e1))]
+        else:
+            plan.sort_pairs(keys, vals, kb, vb if pw else None)
+            tm = plan.timings()
         plan.check()
         rows.append(tm)
     last = rows[-1]
-    total = sum(ms for _, ms in last)
+    total = sum(ms for lab, ms in last if not lab.startswith("whole call"))
     print(json.dumps({"n": n, "tile_items": plan.info.tile_items, "threads": plan.info.threads,
                       "launches": [(lab, round(ms, 4)) for lab, ms in last], "total_ms": round(total, 4),
                       "gkeys_per_s": round(n / total / 1e6, 3)}))

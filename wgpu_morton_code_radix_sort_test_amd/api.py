@@ -207,6 +207,28 @@ class SortPlan:
         )
         return bool(in_b.value)
 
+    def sort_gather(self, keys_a, keys_b, records_in, records_out, record_bytes, n=None, index_a=None, index_b=None,
+                    stream=None):
+        """`mrs_sort_gather`: sorts (key, source index) pairs and moves each record of
+        `record_bytes` once.  Returns (result_in_b, sorted source indices)."""
+        n = self.n if n is None else n
+        if self.payload_bytes != 4:
+            raise ValueError("sort_gather needs a plan with payload_bytes=4")
+        if index_a is None:
+            index_a = torch.empty(max(1, n), dtype=torch.int32, device=self.ctx.device)
+        if index_b is None:
+            index_b = torch.empty(max(1, n), dtype=torch.int32, device=self.ctx.device)
+        self._check_sizes(n, (keys_a, keys_b), (index_a, index_b))
+        if _nbytes(records_in) < n * record_bytes or _nbytes(records_out) < n * record_bytes:
+            raise ValueError("record buffers are too small")
+        in_b = ctypes.c_int(0)
+        _lib.check(
+            self.lib.mrs_sort_gather(self._h, n, _ptr(keys_a), _ptr(keys_b), _ptr(index_a), _ptr(index_b),
+                                     _ptr(records_in), _ptr(records_out), record_bytes, _stream(stream),
+                                     ctypes.byref(in_b))
+        )
+        return bool(in_b.value), (index_b if in_b.value else index_a)
+
     def histogram(self, keys, pass_number, n=None, hist_out=None, stream=None):
         n = self.n if n is None else n
         self._check_sizes(n, (keys,), ())

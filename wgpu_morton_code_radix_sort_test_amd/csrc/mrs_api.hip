@@ -39,6 +39,10 @@ int launch_global_histogram_u32(int bits, int grid, const GlobalHistArgs& a, hip
 int launch_global_histogram_u64(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
 int probe_lds_atomic_order(bool* in_order);
 int probe_die_ids(bool* all_dies);
+// mrs_gather.hip
+int launch_iota(uint32_t* out, uint32_t n, int num_cus, hipStream_t s);
+int launch_gather(const void* in, const uint32_t* index, void* out, uint32_t n, uint32_t record_bytes, int num_cus,
+                  hipStream_t s);
 // mrs_small_sort.hip
 uint32_t small_sort_capacity();
 int launch_small_sort(int key_words, int bits, const SmallSortArgs& a, hipStream_t s);
@@ -559,6 +563,31 @@ extern "C" int mrs_plan_get_timings(mrs_plan* plan, int cap, float* ms_out, char
     }
     *count_out = count;
     return MRS_OK;
+}
+
+extern "C" int mrs_sort_gather(mrs_plan* plan, uint64_t n, void* keys_a, void* keys_b, uint32_t* index_a,
+                               uint32_t* index_b, const void* records_in, void* records_out, uint32_t record_bytes,
+                               void* stream, int* result_in_b)
+{
+    clear_error();
+    if (int rc = validate_call(plan, n, "mrs_sort_gather")) return rc;
+    if (plan->desc.payload_bytes != 4)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_sort_gather: the plan must sort 4-byte payloads (source indices)");
+    if (record_bytes == 0 || record_bytes % 4 != 0)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_sort_gather: record_bytes must be a positive multiple of 4");
+    int in_b = (plan->num_passes % 2u) == 1u;
+    if (result_in_b) *result_in_b = in_b;
+    if (n == 0) return MRS_OK;
+    if (!index_a || !index_b || !records_in || !records_out)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_sort_gather: null buffer");
+    if (records_in == records_out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_sort_gather: records_out aliases records_in");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = launch_iota(index_a, static_cast<uint32_t>(n), plan->ctx->num_cus, s)) return rc;
+    if (int rc = mrs_sort_pairs(plan, n, keys_a, index_a, keys_b, index_b, stream, &in_b)) return rc;
+    if (int rc = launch_gather(records_in, in_b ? index_b : index_a, records_out, static_cast<uint32_t>(n), record_bytes,
+                               plan->ctx->num_cus, s))
+        return rc;
+    return mark(plan, "gather", s);
 }
 
 extern "C" int mrs_histogram(mrs_plan* plan, uint64_t n, const void* keys_dev, uint32_t pass, uint32_t* hist_dev,

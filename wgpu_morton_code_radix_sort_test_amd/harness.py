@@ -26,10 +26,12 @@ class Buffers:
     morton_codes_2: torch.Tensor
     plan: SortPlan
     result_in_2: bool = False
+    triangles_in_2: bool = False  # where the sorted TriangleIndices are (follows result_in_2 unless gathered)
+    source_index: torch.Tensor = None  # gather mode: sorted source indices (u32)
     host: dict = field(default_factory=dict)
 
 
-def create_all_buffers(ctx, positions, indices, generator, num_passes, algo, tile_items=0):
+def create_all_buffers(ctx, positions, indices, generator, num_passes, algo, tile_items=0, gather_payload=False):
     """create_all_buffers (src/main.rs:31-85): uploads vertices/indices/uniforms and
     allocates the second index buffer and the two Morton code buffers."""
     dev = ctx.device
@@ -37,8 +39,8 @@ def create_all_buffers(ctx, positions, indices, generator, num_passes, algo, til
     blob = scene.create_morton_uniforms(generator)
     vertices_b = torch.from_numpy(scene.pack_vertices(positions)).to(dev)
     indices_b = torch.from_numpy(scene.pack_triangles(indices)).to(dev)
-    plan = SortPlan(ctx, n, key_words=2, payload_bytes=16, digit_bits=scene.BITS_PER_PASS, begin_bit=0,
-                    end_bit=8 * num_passes, algo=algo, tile_items=tile_items)
+    plan = SortPlan(ctx, n, key_words=2, payload_bytes=4 if gather_payload else 16, digit_bits=scene.BITS_PER_PASS,
+                    begin_bit=0, end_bit=8 * num_passes, algo=algo, tile_items=tile_items)
     return Buffers(
         vertices=vertices_b,
         indices=indices_b,
@@ -52,19 +54,28 @@ def create_all_buffers(ctx, positions, indices, generator, num_passes, algo, til
 
 
 def run_compute_shaders(ctx, stream=None, num_vertices=scene.NUM_VERTICES, num_triangles=scene.NUM_TRIANGLES,
-                        num_passes=scene.NUM_PASSES, seed=scene.RNG_SEED, algo=ALGO_ONESWEEP, tile_items=0):
+                        num_passes=scene.NUM_PASSES, seed=scene.RNG_SEED, algo=ALGO_ONESWEEP, tile_items=0,
+                        gather_payload=False):
     """Enqueues Morton coding + the radix sort on `stream`; returns the Buffers.
 
-    Like the reference function it only records work: nothing is synchronised.
+    Like the reference function it only records work: nothing is synchronised.  With
+    `gather_payload` the TriangleIndices records are not carried through the passes: (code,
+    source index) pairs are sorted and every record moves once, into `indices_2`.
     """
     positions, indices, generator = scene.create_scene(num_vertices, num_triangles, seed)
-    buffers = create_all_buffers(ctx, positions, indices, generator, num_passes, algo, tile_items)
+    buffers = create_all_buffers(ctx, positions, indices, generator, num_passes, algo, tile_items, gather_payload)
     # "Morton Coding", src/main.rs:581-592
     ctx.morton_encode_lut(buffers.morton_uniforms, buffers.vertices, buffers.indices, buffers.morton_codes,
                           stream=stream)
     # NUM_PASSES x {histogram, prefix sums, indexing}, src/main.rs:594-665
-    buffers.result_in_2 = buffers.plan.sort_pairs(buffers.morton_codes, buffers.indices, buffers.morton_codes_2,
-                                                  buffers.indices_2, stream=stream)
+    if gather_payload:
+        buffers.result_in_2, buffers.source_index = buffers.plan.sort_gather(
+            buffers.morton_codes, buffers.morton_codes_2, buffers.indices, buffers.indices_2, 16, stream=stream)
+        buffers.triangles_in_2 = True
+    else:
+        buffers.result_in_2 = buffers.plan.sort_pairs(buffers.morton_codes, buffers.indices, buffers.morton_codes_2,
+                                                      buffers.indices_2, stream=stream)
+        buffers.triangles_in_2 = buffers.result_in_2
     return buffers
 
 
@@ -85,7 +96,7 @@ def run_headless(device=0, **kwargs):
     buffers = run_compute_shaders(ctx, **kwargs)
     buffers.plan.check()  # synchronises; raises on a device-side timeout
     out_codes = buffers.morton_codes_2 if buffers.result_in_2 else buffers.morton_codes
-    out_tris = buffers.indices_2 if buffers.result_in_2 else buffers.indices
+    out_tris = buffers.indices_2 if buffers.triangles_in_2 else buffers.indices
     keys = out_codes.cpu().numpy().view(np.uint64)
     tris = out_tris.cpu().numpy().view(np.uint32).reshape(-1, 4)[:, :3]
     sel = select_bits(keys, num_passes)
