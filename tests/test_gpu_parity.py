@@ -442,6 +442,20 @@ def test_run_headless(ctx, oracle, mrs, algo_name):
     assert np.array_equal(res["triangles"], rv.reshape(-1, 4)[:, :3])
 
 
+def test_run_headless_chacha8_scene(ctx, oracle, mrs):
+    """The shipped scene size from the restated ChaCha8 stream: sorted, and equal to the checker."""
+    res = mrs.run_headless(0, scene_rng="chacha8")
+    assert res["sorted"] and not res["all_zero"]
+    host = res["buffers"].host
+    verts = mrs.scene.pack_vertices(host["positions"])
+    tris = mrs.scene.pack_triangles(host["indices"])
+    codes = oracle.morton_encode_lut(host["uniforms"], verts, tris)
+    n = host["indices"].shape[0]
+    rk, rv, _ = oracle.lsd_sort(codes, tris.view(np.uint32), n, 2, 4, 8, 0, 64, 256)
+    assert np.array_equal(res["keys"].view(np.uint32), rk)
+    assert np.array_equal(res["triangles"], rv.reshape(-1, 4)[:, :3])
+
+
 @pytest.mark.parametrize("num_triangles", [3000, 70001])
 def test_run_headless_gathered_payload(ctx, oracle, mrs, num_triangles):
     """The same entry point with the TriangleIndices moved once at the end instead of through

@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from wgpu_morton_code_radix_sort_test_amd import _lib, scene
 from wgpu_morton_code_radix_sort_test_amd.dist import bucket_to_rank_map
@@ -125,3 +126,65 @@ def test_bucket_to_rank_map():
     counts[9] = 5
     table = bucket_to_rank_map(counts, 4)
     assert np.bincount(table, weights=counts, minlength=4).max() == 5
+
+
+# ---- the reference's random stream (ChaCha8Rng::seed_from_u64), restated ----------------------------
+def test_chacha8_block_known_answer():
+    """ChaCha with 8 rounds, all-zero key, counter 0, zero stream id: first 32 output bytes of the
+    published test vector for that configuration."""
+    from wgpu_morton_code_radix_sort_test_amd.scene import ChaCha8Rng
+
+    rng = ChaCha8Rng(key_bytes=bytes(32))
+    got = rng.blocks(0, 1).astype("<u4").tobytes()[:32].hex()
+    assert got == "3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e"
+    # the stream is the blocks in counter order, whatever the batch size
+    a = ChaCha8Rng(7).next_u32_array(200)
+    r = ChaCha8Rng(7)
+    b = np.concatenate([r.next_u32_array(k) for k in (1, 15, 16, 17, 64, 87)])
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[:16], ChaCha8Rng(7).blocks(0, 1)) and np.array_equal(a[16:32], ChaCha8Rng(7).blocks(1, 1))
+
+
+def test_seed_from_u64_is_pcg32():
+    from wgpu_morton_code_radix_sort_test_amd.scene import ChaCha8Rng
+
+    seed = ChaCha8Rng.seed_bytes_from_u64(7)
+    assert len(seed) == 32 and seed != ChaCha8Rng.seed_bytes_from_u64(8)
+    # first word by hand: one LCG step, xorshift-high, rotate right by the top 5 bits
+    state = (7 * 6364136223846793005 + 11634580027462260723) % (1 << 64)
+    xs = (((state >> 18) ^ state) >> 27) & 0xFFFFFFFF
+    rot = state >> 59
+    word = ((xs >> rot) | (xs << ((32 - rot) % 32))) & 0xFFFFFFFF
+    assert int.from_bytes(seed[:4], "little") == word
+
+
+@pytest.mark.parametrize("high", [1000, 3, (1 << 31) + 1, (1 << 32) - 5])
+def test_uniform_u32_matches_the_scalar_loop(high):
+    """Batch sampling with rejections consumes the stream exactly like one draw at a time."""
+    from wgpu_morton_code_radix_sort_test_amd.scene import ChaCha8Rng
+
+    fast = ChaCha8Rng(11).sample_uniform_u32(high, 500)
+    slow_rng = ChaCha8Rng(11)
+    zone = 0xFFFFFFFF - ((1 << 32) - high) % high
+    slow = []
+    while len(slow) < 500:
+        v = int(slow_rng.next_u32_array(1)[0]) * high
+        if (v & 0xFFFFFFFF) <= zone:
+            slow.append(v >> 32)
+    assert np.array_equal(fast, np.asarray(slow, dtype=np.uint32))
+    assert int(fast.max()) < high
+
+
+def test_create_scene_chacha8():
+    from wgpu_morton_code_radix_sort_test_amd import scene
+
+    pos, idx, gen = scene.create_scene_chacha8()
+    assert pos.shape == (scene.NUM_VERTICES, 3) and idx.shape == (scene.NUM_TRIANGLES, 3)
+    assert pos.dtype == np.float32 and float(pos.min()) >= 0.0 and float(pos.max()) < 1.0
+    assert int(idx.max()) < scene.NUM_VERTICES
+    # positions are multiples of 2^-24 (24 random bits), as Standard f32 makes them
+    assert np.array_equal(pos * np.float32(1 << 24), np.floor(pos * np.float32(1 << 24)))
+    used = pos[idx.reshape(-1)]
+    assert np.allclose(gen.offset, used.min(axis=0))
+    pos2, idx2, _ = scene.create_scene_chacha8()
+    assert np.array_equal(pos, pos2) and np.array_equal(idx, idx2)

@@ -55,14 +55,17 @@ def create_all_buffers(ctx, positions, indices, generator, num_passes, algo, til
 
 def run_compute_shaders(ctx, stream=None, num_vertices=scene.NUM_VERTICES, num_triangles=scene.NUM_TRIANGLES,
                         num_passes=scene.NUM_PASSES, seed=scene.RNG_SEED, algo=ALGO_ONESWEEP, tile_items=0,
-                        gather_payload=False):
+                        gather_payload=False, scene_rng="counter"):
     """Enqueues Morton coding + the radix sort on `stream`; returns the Buffers.
 
     Like the reference function it only records work: nothing is synchronised.  With
     `gather_payload` the TriangleIndices records are not carried through the passes: (code,
     source index) pairs are sorted and every record moves once, into `indices_2`.
     """
-    positions, indices, generator = scene.create_scene(num_vertices, num_triangles, seed)
+    # scene_rng="chacha8": the reference's ChaCha8Rng stream as restated in scene.ChaCha8Rng
+    # (unverified against the Rust crates); "counter": this package's counter-based generator
+    make_scene = scene.create_scene_chacha8 if scene_rng == "chacha8" else scene.create_scene
+    positions, indices, generator = make_scene(num_vertices, num_triangles, seed)
     buffers = create_all_buffers(ctx, positions, indices, generator, num_passes, algo, tile_items, gather_payload)
     # "Morton Coding", src/main.rs:581-592
     ctx.morton_encode_lut(buffers.morton_uniforms, buffers.vertices, buffers.indices, buffers.morton_codes,

@@ -180,6 +180,118 @@ def pack_triangles(indices):
     return rec.reshape(-1).view(np.uint8)
 
 
+class ChaCha8Rng:
+    """`rand_chacha::ChaCha8Rng::seed_from_u64` as the reference seeds it (src/main.rs:124),
+    restated from the published algorithms; NOT checked against the Rust crates (no Rust
+    toolchain or crate sources here), so scenes made with it are labelled unverified.
+
+    * seed expansion (rand_core 0.6 `SeedableRng::seed_from_u64`): eight PCG32 outputs
+      (multiplier 6364136223846793005, increment 11634580027462260723, XSH-RR), little
+      endian, form the 32-byte key;
+    * ChaCha with 8 rounds, 64-bit block counter in words 12-13, stream id 0 in words 14-15;
+      the output words of consecutive blocks are consumed in order as `next_u32`;
+    * `gen::<f32>()` (rand 0.8 `Standard`): `(next_u32() >> 8) * 2^-24`;
+    * `Uniform::new(0, n).sample()` for u32 (rand 0.8.5 `UniformInt`): widening multiply of a
+      u32 draw by n, accepted when the low half is at most `u32::MAX - ((2^32 - n) % n)`.
+    """
+
+    _SIGMA = (0x61707865, 0x3320646E, 0x79622D32, 0x6B206574)
+
+    def __init__(self, seed_u64=None, key_bytes=None):
+        if key_bytes is None:
+            key_bytes = self.seed_bytes_from_u64(seed_u64)
+        self.key = np.frombuffer(bytes(key_bytes), dtype="<u4").astype(np.uint32)
+        self.counter = 0
+        self._words = np.zeros(0, dtype=np.uint32)
+        self._at = 0
+
+    @staticmethod
+    def seed_bytes_from_u64(state):
+        mask = (1 << 64) - 1
+        out = bytearray()
+        for _ in range(8):
+            state = (state * 6364136223846793005 + 11634580027462260723) & mask
+            xorshifted = (((state >> 18) ^ state) >> 27) & 0xFFFFFFFF
+            rot = state >> 59
+            x = ((xorshifted >> rot) | (xorshifted << ((32 - rot) & 31))) & 0xFFFFFFFF
+            out += int(x).to_bytes(4, "little")
+        return bytes(out)
+
+    def blocks(self, first_counter, count):
+        """`count` consecutive 16-word output blocks starting at block `first_counter`."""
+        ctr = np.arange(first_counter, first_counter + count, dtype=np.uint64)
+        x = np.empty((16, count), dtype=np.uint32)
+        for i in range(4):
+            x[i] = self._SIGMA[i]
+        for i in range(8):
+            x[4 + i] = self.key[i]
+        x[12] = (ctr & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        x[13] = (ctr >> np.uint64(32)).astype(np.uint32)
+        x[14] = 0
+        x[15] = 0
+        init = x.copy()
+
+        def rotl(v, r):
+            return (v << np.uint32(r)) | (v >> np.uint32(32 - r))
+
+        def quarter(a, b, c, d):
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16)
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12)
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8)
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7)
+
+        with np.errstate(over="ignore"):
+            for _ in range(4):  # 8 rounds = 4 double rounds
+                quarter(0, 4, 8, 12); quarter(1, 5, 9, 13); quarter(2, 6, 10, 14); quarter(3, 7, 11, 15)
+                quarter(0, 5, 10, 15); quarter(1, 6, 11, 12); quarter(2, 7, 8, 13); quarter(3, 4, 9, 14)
+            x += init
+        return x.T.reshape(-1)  # block-major, word order inside a block
+
+    def next_u32_array(self, count):
+        """The next `count` outputs of `next_u32`."""
+        out = np.empty(count, dtype=np.uint32)
+        filled = 0
+        while filled < count:
+            if self._at == self._words.size:
+                nblocks = max(4, min(1 << 16, (count - filled + 15) // 16))
+                self._words = self.blocks(self.counter, nblocks)
+                self.counter += nblocks
+                self._at = 0
+            take = min(count - filled, self._words.size - self._at)
+            out[filled:filled + take] = self._words[self._at:self._at + take]
+            self._at += take
+            filled += take
+        return out
+
+    def gen_f32(self, count):
+        return (self.next_u32_array(count) >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+
+    def sample_uniform_u32(self, high, count):
+        """`Uniform::new(0, high)` sampled `count` times: the accepted draws of the stream, in order."""
+        zone = 0xFFFFFFFF - ((1 << 32) - high) % high
+        out = np.empty(count, dtype=np.uint32)
+        filled = 0
+        while filled < count:
+            # never more draws than results still missing: the stream position after the call is
+            # then the one the scalar loop leaves
+            v = self.next_u32_array(count - filled).astype(np.uint64) * np.uint64(high)
+            kept = (v[(v & np.uint64(0xFFFFFFFF)) <= np.uint64(zone)] >> np.uint64(32)).astype(np.uint32)
+            out[filled:filled + kept.size] = kept
+            filled += kept.size
+        return out
+
+
+def create_scene_chacha8(num_vertices=NUM_VERTICES, num_triangles=NUM_TRIANGLES, seed=RNG_SEED):
+    """`create_scene` with the reference's random stream (src/main.rs:124-161): positions are
+    three `gen::<f32>()` per vertex, then three `Uniform(0, NUM_VERTICES)` draws per triangle from
+    the same generator.  Unverified against the Rust crates: see ChaCha8Rng."""
+    rng = ChaCha8Rng(seed)
+    positions = rng.gen_f32(3 * num_vertices).reshape(num_vertices, 3)
+    indices = rng.sample_uniform_u32(num_vertices, 3 * num_triangles).reshape(num_triangles, 3)
+    used = positions[indices.reshape(-1)]
+    return positions, indices, StandInMortonGenerator(used.min(axis=0), used.max(axis=0))
+
+
 def create_scene(num_vertices=NUM_VERTICES, num_triangles=NUM_TRIANGLES, seed=RNG_SEED):
     """Random vertices in [0,1)^3 and triangles of random vertex indices; scene bounds
     over the vertices that triangles use (src/main.rs:114-173).
