@@ -260,6 +260,22 @@ def main():
         enc_ms = e0.elapsed_time(e1) / 5
         extra["morton_encode30_ms"] = round(enc_ms, 4)
         extra["morton_encode30_GBps"] = 20.0 * n / (enc_ms * 1e-3) / 1e9
+        # encode + sort as one pipeline, with the encoder that leaves the digit histograms in the
+        # plan (the sort then skips its own read of the keys) and without; not part of `value`
+        for label, primed in (("encode_then_sort_ms", False), ("encode_for_sort_then_sort_ms", True)):
+            times = []
+            for _ in range(4):
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record()
+                if primed:
+                    plan.morton_encode30_for_sort(xyz, mn, mx, ek, ei)
+                else:
+                    ctx.morton_encode30(xyz, mn, mx, ek, ei)
+                plan.sort_pairs(ek, ei, kb, vb)
+                p1.record()
+                torch.cuda.synchronize()
+                times.append(p0.elapsed_time(p1))
+            extra[label] = round(float(np.median(times[1:])), 4)
         del xyz, ek, ei
 
     if distributed:

@@ -176,6 +176,15 @@ int mrs_scatter(mrs_plan* plan, uint64_t n, const void* keys_in, const void* val
                 void* keys_out, void* vals_out, const uint32_t* scanned_hist_dev,
                 uint32_t pass, void* stream);
 
+/* mrs_morton_encode30 that also leaves the digit histograms of the keys it writes in `plan` (an
+ * MRS_ALGO_ONESWEEP plan for 32-bit keys), so that the next mrs_sort_pairs(plan, n, keys_dev, ...)
+ * with the same keys pointer and n skips its own read of the keys (the histogram launch before the
+ * passes, src/main.rs:594-603 being the reference's per-pass counterpart).  The keys must reach
+ * that call unchanged; any other mrs_sort_pairs call on the plan drops the histograms.  The plan's
+ * memory is used, so the call must be ordered before the sort on one stream. */
+int mrs_morton_encode30_for_sort(mrs_plan* plan, const float* xyz_dev, uint64_t n, const float* mn,
+                                 const float* mx, uint32_t* keys_dev, uint32_t* idx_dev, void* stream);
+
 /* Sort by key, moving each wide record once: the variant the reference's own comments
  * anticipate for TriangleIndices (src/types.rs:26-36, src/shaders/radix_sort_index.wgsl:3-6)
  * instead of carrying 16 bytes through every pass (radix_sort_index.wgsl:281-307).  `plan` must

@@ -306,6 +306,36 @@ def test_sort_gather_matches_oracle(ctx, oracle, mrs, key_words, record_words):
         plan.close()
 
 
+@pytest.mark.parametrize("bits,begin,end", [(8, 0, 32), (8, 0, 30), (4, 0, 30), (8, 3, 27)])
+def test_encode_for_sort_primes_the_plan(ctx, oracle, mrs, bits, begin, end):
+    """The encoder that leaves the digit histograms in the plan: same keys as the plain encoder,
+    and the sort that follows (which then skips its histogram launch) gives the checker's result;
+    a later sort of other keys with the same plan is not affected."""
+    n = 200003
+    xyz = oracle.gen_points(5, n)
+    mn, mx = oracle.minmax3(xyz)
+    rk, ri = oracle.morton_encode30(xyz, mn, mx)
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=bits, begin_bit=begin, end_bit=end)
+    plan.set_timing(True)
+    keys, idx = plan.morton_encode30_for_sort(to_dev(xyz, ctx.device), mn, mx)
+    assert np.array_equal(to_u32(keys), rk) and np.array_equal(to_u32(idx), ri)
+    kb, vb = torch.empty_like(keys), torch.empty_like(idx)
+    in_b = plan.sort_pairs(keys, idx, kb, vb)
+    plan.check()
+    assert "global_histogram" not in [lab for lab, _ in plan.timings()]
+    sk, sv = oracle.stable_sort_pairs(rk, ri, n, 1, 1, begin, end)
+    assert np.array_equal(to_u32(kb if in_b else keys), sk) and np.array_equal(to_u32(vb if in_b else idx), sv)
+    # the histograms are used once: the next sort computes its own
+    other = make_keys(oracle, n, 1, "random")
+    ok, ov = to_dev(other, ctx.device), to_dev(ri, ctx.device)
+    in_b = plan.sort_pairs(ok, ov, kb, vb)
+    plan.check()
+    assert "global_histogram" in [lab for lab, _ in plan.timings()]
+    sk, sv = oracle.stable_sort_pairs(other, ri, n, 1, 1, begin, end)
+    assert np.array_equal(to_u32(kb if in_b else ok), sk) and np.array_equal(to_u32(vb if in_b else ov), sv)
+    plan.close()
+
+
 def test_context_attributes(ctx):
     assert ctx.attribute(ctx.ATTR_COMPUTE_UNITS) == 256
     # gfx950 serves the lanes of a returning LDS atomic in lane order; the creation-time check sees it

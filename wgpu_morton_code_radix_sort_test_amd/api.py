@@ -207,6 +207,27 @@ class SortPlan:
         )
         return bool(in_b.value)
 
+    def morton_encode30_for_sort(self, xyz, mn, mx, keys_out=None, idx_out=None, stream=None):
+        """`mrs_morton_encode30_for_sort`: the encoder that also leaves the digit histograms of the
+        keys in this plan; pass the returned key tensor to sort_pairs as keys_a, unchanged."""
+        n = xyz.numel() // 3
+        if xyz.dtype != torch.float32:
+            raise ValueError("xyz must be float32")
+        if keys_out is None:
+            keys_out = torch.empty(n, dtype=torch.int32, device=self.ctx.device)
+        if idx_out is None:
+            idx_out = torch.empty(n, dtype=torch.int32, device=self.ctx.device)
+        if keys_out.numel() < n or idx_out.numel() < n:
+            raise ValueError("output tensors are too small")
+        c3 = ctypes.c_float * 3
+        _lib.check(
+            self.lib.mrs_morton_encode30_for_sort(
+                self._h, _ptr(xyz), n, c3(*[float(v) for v in mn]), c3(*[float(v) for v in mx]),
+                _ptr(keys_out), _ptr(idx_out), _stream(stream),
+            )
+        )
+        return keys_out, idx_out
+
     def sort_gather(self, keys_a, keys_b, records_in, records_out, record_bytes, n=None, index_a=None, index_b=None,
                     stream=None):
         """`mrs_sort_gather`: sorts (key, source index) pairs and moves each record of

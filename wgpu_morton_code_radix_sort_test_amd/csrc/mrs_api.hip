@@ -39,6 +39,10 @@ int launch_global_histogram_u32(int bits, int grid, const GlobalHistArgs& a, hip
 int launch_global_histogram_u64(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
 int probe_lds_atomic_order(bool* in_order);
 int probe_die_ids(bool* all_dies);
+// mrs_morton.hip
+int launch_encode30_with_histogram(int num_cus, const float* xyz_dev, uint64_t n, const float* mn, const float* mx,
+                                   uint32_t* keys_dev, uint32_t* idx_dev, uint32_t* ghist, uint32_t begin_bit,
+                                   uint32_t end_bit, uint32_t bits, uint32_t num_passes, hipStream_t s);
 // mrs_gather.hip
 int launch_iota(uint32_t* out, uint32_t n, int num_cus, hipStream_t s);
 int launch_gather(const void* in, const uint32_t* index, void* out, uint32_t n, uint32_t record_bytes, int num_cus,
@@ -446,6 +450,9 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
 
+    // histograms left by mrs_morton_encode30_for_sort for exactly these keys?
+    const bool primed = plan->primed_keys == keys_a && plan->primed_n == n && plan->desc.algo == MRS_ALGO_ONESWEEP;
+    plan->primed_keys = nullptr;
     plan->num_marks = 0;
     if (int rc = mark(plan, "start", s)) return rc;
     // Small inputs: the whole sort in one launch of one workgroup (MRS_NO_SMALL_SORT=1: A/B aid).
@@ -468,7 +475,9 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
     if (plan->desc.algo == MRS_ALGO_ONESWEEP) {
         const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
         const size_t zero = kControlBytes + align_up(region * plan->num_passes, 256);
-        MRS_HIP_TRY(hipMemsetAsync(plan->zero_begin, 0, zero, s));
+        // a primed plan keeps its histograms: only the ticket counters and the status words are cleared
+        const size_t keep = primed ? offsetof(OnesweepControl, tile_counter) : 0;
+        MRS_HIP_TRY(hipMemsetAsync(plan->zero_begin + keep, 0, zero - keep, s));
         if (int rc = mark(plan, "memset", s)) return rc;
         GlobalHistArgs h{};
         h.keys = keys_a;
@@ -479,8 +488,10 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
         h.digit_map = nullptr;
         h.map_mask = 0;
         h.ghist = plan->control->ghist;
-        if (int rc = launch_global_hist(plan, h, s)) return rc;
-        if (int rc = mark(plan, "global_histogram", s)) return rc;
+        if (!primed) {
+            if (int rc = launch_global_hist(plan, h, s)) return rc;
+            if (int rc = mark(plan, "global_histogram", s)) return rc;
+        }
         if (int rc = launch_ghist_scan(plan, plan->num_passes, s)) return rc;
         if (int rc = mark(plan, "histogram_scan", s)) return rc;
     }
@@ -562,6 +573,28 @@ extern "C" int mrs_plan_get_timings(mrs_plan* plan, int cap, float* ms_out, char
         ++count;
     }
     *count_out = count;
+    return MRS_OK;
+}
+
+extern "C" int mrs_morton_encode30_for_sort(mrs_plan* plan, const float* xyz_dev, uint64_t n, const float* mn,
+                                            const float* mx, uint32_t* keys_dev, uint32_t* idx_dev, void* stream)
+{
+    clear_error();
+    if (int rc = validate_call(plan, n, "mrs_morton_encode30_for_sort")) return rc;
+    if (plan->desc.key_words != 1 || plan->desc.algo != MRS_ALGO_ONESWEEP)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30_for_sort: the plan must be an onesweep plan for 32-bit keys");
+    if (n == 0) return MRS_OK;
+    if (!xyz_dev || !mn || !mx || !keys_dev || !idx_dev)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30_for_sort: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    plan->primed_keys = nullptr;
+    MRS_HIP_TRY(hipMemsetAsync(plan->control->ghist, 0, sizeof(plan->control->ghist), s));
+    if (int rc = launch_encode30_with_histogram(plan->ctx->num_cus, xyz_dev, n, mn, mx, keys_dev, idx_dev,
+                                                plan->control->ghist, plan->desc.begin_bit, plan->desc.end_bit,
+                                                plan->radix_bits, plan->num_passes, s))
+        return rc;
+    plan->primed_keys = keys_dev;
+    plan->primed_n = n;
     return MRS_OK;
 }
 

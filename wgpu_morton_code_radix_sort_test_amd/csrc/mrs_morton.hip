@@ -110,11 +110,31 @@ struct Bounds3 {
     float mx[3];
 };
 
+// Digit histograms of the keys being written, for the sort that follows (see
+// mrs_morton_encode30_for_sort): same content as global_histogram_kernel produces.
+struct EncodeHistogram {
+    uint32_t* ghist;  // [num_passes][1 << bits], zeroed
+    uint32_t begin_bit, end_bit, bits, num_passes;
+};
+
 // Each thread encodes 4 consecutive points = 48 bytes = three 16-byte loads.
+template <bool HIST>
 __global__ __launch_bounds__(256) void morton_encode30_kernel(const float* __restrict__ xyz, unsigned long long n,
                                                                const Bounds3 b, uint32_t* __restrict__ keys,
-                                                               uint32_t* __restrict__ idx)
+                                                               uint32_t* __restrict__ idx, const EncodeHistogram h)
 {
+    __shared__ uint32_t s_hist[HIST ? 1024 : 1];  // 4 x 256 or 8 x 16 counters (32-bit keys)
+    if constexpr (HIST) {
+        for (int j = threadIdx.x; j < 1024; j += 256) s_hist[j] = 0;
+        __syncthreads();
+    }
+    auto count = [&](uint32_t k) {
+        for (uint32_t p = 0; p < h.num_passes; ++p) {
+            const uint32_t shift = h.begin_bit + p * h.bits;
+            const uint32_t width = h.end_bit - shift < h.bits ? h.end_bit - shift : h.bits;
+            atomicAdd(&s_hist[(p << h.bits) + ((k >> shift) & ((1u << width) - 1u))], 1u);
+        }
+    };
     const float ext[3] = {b.mx[0] - b.mn[0], b.mx[1] - b.mn[1], b.mx[2] - b.mn[2]};
     const unsigned long long groups = (n + 3) / 4;
     const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256;
@@ -147,12 +167,24 @@ __global__ __launch_bounds__(256) void morton_encode30_kernel(const float* __res
             *reinterpret_cast<uint4*>(keys + first) = make_uint4(k[0], k[1], k[2], k[3]);
             const uint32_t i0 = static_cast<uint32_t>(first);
             *reinterpret_cast<uint4*>(idx + first) = make_uint4(i0, i0 + 1, i0 + 2, i0 + 3);
+            if constexpr (HIST) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) count(k[q]);
+            }
         } else {
             for (int q = 0; q < 4; ++q)
                 if (first + q < n) {
                     keys[first + q] = k[q];
                     idx[first + q] = static_cast<uint32_t>(first + q);
+                    if constexpr (HIST) count(k[q]);
                 }
+        }
+    }
+    if constexpr (HIST) {
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < (h.num_passes << h.bits); j += 256) {
+            const uint32_t c = s_hist[j];
+            if (c) atomicAdd(&h.ghist[j], c);
         }
     }
 }
@@ -244,12 +276,37 @@ extern "C" int mrs_morton_encode30(mrs_context* ctx, const float* xyz_dev, uint6
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30: buffers must be 16-byte aligned");
     Bounds3 b;
     for (int c = 0; c < 3; ++c) { b.mn[c] = mn[c]; b.mx[c] = mx[c]; }
-    hipLaunchKernelGGL(morton_encode30_kernel, dim3(grid_for((n + 3) / 4, ctx->num_cus)), dim3(256), 0,
+    hipLaunchKernelGGL(morton_encode30_kernel<false>, dim3(grid_for((n + 3) / 4, ctx->num_cus)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), xyz_dev, static_cast<unsigned long long>(n), b, keys_dev,
-                       idx_dev);
+                       idx_dev, EncodeHistogram{});
     MRS_CHECK_LAUNCH("morton_encode30_kernel");
     return MRS_OK;
 }
+
+namespace mrs {
+// The encoder with the digit histograms of a 32-bit-key plan accumulated on the way (called by
+// mrs_morton_encode30_for_sort in mrs_api.hip, which owns the plan's memory).
+int launch_encode30_with_histogram(int num_cus, const float* xyz_dev, uint64_t n, const float* mn, const float* mx,
+                                   uint32_t* keys_dev, uint32_t* idx_dev, uint32_t* ghist, uint32_t begin_bit,
+                                   uint32_t end_bit, uint32_t bits, uint32_t num_passes, hipStream_t s)
+{
+    if ((reinterpret_cast<uintptr_t>(xyz_dev) | reinterpret_cast<uintptr_t>(keys_dev) |
+         reinterpret_cast<uintptr_t>(idx_dev)) & 15u)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30_for_sort: buffers must be 16-byte aligned");
+    Bounds3 b;
+    for (int c = 0; c < 3; ++c) { b.mn[c] = mn[c]; b.mx[c] = mx[c]; }
+    const EncodeHistogram h{ghist, begin_bit, end_bit, bits, num_passes};
+    // fewer, longer-lived workgroups than the plain encoder: each ends with up to 1024 global atomics
+    uint64_t blocks = ((n + 3) / 4 + 256 * 8 - 1) / (256 * 8);
+    const uint64_t cap = static_cast<uint64_t>(num_cus) * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(morton_encode30_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, xyz_dev,
+                       static_cast<unsigned long long>(n), b, keys_dev, idx_dev, h);
+    MRS_CHECK_LAUNCH("morton_encode30_kernel<histogram>");
+    return MRS_OK;
+}
+}  // namespace mrs
 
 extern "C" int mrs_generate_points(mrs_context* ctx, uint64_t seed, uint64_t n, float* xyz_dev, void* stream)
 {
