@@ -257,7 +257,7 @@ def test_sort_fuzz(ctx, oracle, mrs):
     tiles_small = {(1, 0): [0, 256, 1024, 4096, 8192, 16384, 32768], (1, 1): [0, 256, 1024, 4096, 8192, 16384, 32768],
                    (2, 0): [0, 256, 1024, 4096, 16384], (2, 1): [0, 256, 1024, 4096, 16384],
                    (2, 4): [0, 256, 1024, 4096, 8192], (1, 4): [0, 256, 1024, 4096, 8192]}
-    for case in range(60):
+    for case in range(int(os.environ.get("MRS_FUZZ_CASES", "60"))):
         key_words, payload_words = [(1, 0), (1, 1), (2, 0), (2, 1), (2, 4), (1, 4)][rng.randint(6)]
         bits = int(rng.choice([4, 8]))
         key_bits = 32 * key_words
