@@ -158,7 +158,11 @@ int mrs_morton_encode30(mrs_context* ctx, const float* xyz_dev, uint64_t n,
  * (keys_b, vals_b), pass 1 the other way round, and so on.  *result_in_b is set
  * (on the host, immediately) to 1 when the sorted data ends in the B buffers,
  * i.e. when the number of passes is odd (src/main.rs:819-823).  n <= plan n.
- * vals_* may be NULL when payload_bytes == 0. */
+ * vals_* may be NULL when payload_bytes == 0.  The pair of buffers that does
+ * not hold the result is scratch.  MRS_ALGO_ONESWEEP plans for 64-bit keys
+ * leave out, on the device, passes whose digit is the same for every key (the
+ * constant high bytes of a short code); they are left out in pairs, so the
+ * result side stays the one reported here. */
 int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a,
                    void* keys_b, void* vals_b, void* stream, int* result_in_b);
 

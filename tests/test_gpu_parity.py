@@ -374,6 +374,44 @@ def test_sort_large_tile_u64_keys(ctx, oracle, mrs):
         assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
 
 
+# (mask of the low word, mask of the high word): which bytes of a 64-bit key vary
+LIVE_BYTES = [
+    (0xFFFFFFFF, 0x00000000),  # passes 4-7 move nothing (even count: all four are left out)
+    (0xFFFFFFFF, 0x000000FF),  # passes 5-7 (odd count: the last of them runs after all)
+    (0xFF00FFFF, 0xFFFFFFFF),  # pass 2 alone (runs after all)
+    (0xFF0000FF, 0xFFFFFFFF),  # passes 1 and 2
+    (0xFFFF00FF, 0x00FFFFFF),  # passes 1 and 7: the passes between read from the other side
+    (0x00FFFF00, 0xFF0000FF),  # passes 0, 3, 5, 6
+    (0x00000000, 0x00000000),  # every pass
+    (0x000F0000, 0x00000000),  # one live nibble
+]
+
+
+@pytest.mark.parametrize("payload_words", [1, 4])
+@pytest.mark.parametrize("lo_mask,hi_mask", LIVE_BYTES)
+def test_u64_passes_left_out(ctx, oracle, mrs, monkeypatch, lo_mask, hi_mask, payload_words):
+    """64-bit keys some of whose bytes are the same for every key: the device leaves those
+    passes out (in pairs, so that the result still lands on the promised side) and the passes
+    after them read from the other buffer pair.  Results must not change, with 8- and 4-bit
+    digits, with an odd number of passes, and on the general path for a small input."""
+    n = 50021
+    keys = make_keys(oracle, n, 2, "random").reshape(n, 2).copy()
+    keys[:, 0] = (keys[:, 0] & np.uint32(lo_mask)) | np.uint32(0x12345678 & ~lo_mask & 0xFFFFFFFF)
+    keys[:, 1] = (keys[:, 1] & np.uint32(hi_mask)) | np.uint32(0x9ABCDEF0 & ~hi_mask & 0xFFFFFFFF)
+    keys = keys.reshape(-1)
+    vals = make_vals(oracle, n, payload_words)
+    for bits, begin, end in ((8, 0, 64), (4, 0, 64), (8, 0, 40), (8, 8, 64)):
+        ko, vo, in_b = gpu_sort(ctx, mrs, keys, vals, n, 2, payload_words, bits, begin, end, mrs.ALGO_ONESWEEP)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 2, payload_words, begin, end)
+        assert np.array_equal(ko, rk) and np.array_equal(vo, rv), (bits, begin, end)
+        assert in_b == ((-(-(end - begin) // bits)) % 2 == 1)
+    monkeypatch.setenv("MRS_NO_SMALL_SORT", "1")
+    m = 777
+    ko, vo, _ = gpu_sort(ctx, mrs, keys[: 2 * m], vals[: m * payload_words], m, 2, payload_words, 8, 0, 64, mrs.ALGO_ONESWEEP)
+    rk, rv = oracle.stable_sort_pairs(keys[: 2 * m], vals[: m * payload_words], m, 2, payload_words, 0, 64)
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
 @pytest.mark.parametrize("tile", [256, 1024])
 @pytest.mark.parametrize("dist", ["random", "all_equal"])
 def test_onesweep_long_chains(ctx, oracle, mrs, tile, dist):

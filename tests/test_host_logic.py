@@ -188,3 +188,18 @@ def test_create_scene_chacha8():
     assert np.allclose(gen.offset, used.min(axis=0))
     pos2, idx2, _ = scene.create_scene_chacha8()
     assert np.array_equal(pos, pos2) and np.array_equal(idx, idx2)
+
+
+def test_built_kernels_have_no_select_on_a_stale_condition_code():
+    """The machine code of libmrs.so is scanned for a miscompile ROCm 7.2's compiler has produced
+    from correct source (a scalar select that reads the carry of an unrelated add instead of the
+    comparison it belongs to; see tools/check_scc.py).  The scan needs no GPU."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "wgpu_morton_code_radix_sort_test_amd", "csrc", "libmrs.so")
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump in this image")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_scc.py"), lib], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]

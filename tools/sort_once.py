@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--key-words", type=int, default=1)
     ap.add_argument("--payload-bytes", type=int, default=4)
     ap.add_argument("--dist", default="morton30", choices=["morton30", "random", "sorted", "equal"])
+    ap.add_argument("--hi-mask", type=lambda v: int(v, 0), default=0xFFFFFFFF,
+                    help="64-bit keys: mask applied to the high word (short codes have constant high bytes)")
     ap.add_argument("--gather", action="store_true",
                     help="sort (key, source index) and move each record of --payload-bytes once (mrs_sort_gather)")
     args = ap.parse_args()
@@ -45,7 +47,10 @@ def main():
             keys, idx = ctx.morton_encode30(xyz, mn, mx)
             del xyz
             if kw == 2:
-                keys = torch.stack([keys, ctx.generate_u32(3, it, n)], dim=1).reshape(-1).contiguous()
+                hi = ctx.generate_u32(3, it, n)
+                if args.hi_mask != 0xFFFFFFFF:
+                    hi &= args.hi_mask if args.hi_mask < (1 << 31) else args.hi_mask - (1 << 32)
+                keys = torch.stack([keys, hi], dim=1).reshape(-1).contiguous()
         else:
             keys = ctx.generate_u32(7 + it, 1, n * kw)
             if args.dist == "sorted":

@@ -158,13 +158,17 @@ static int launch_global_hist(const mrs_plan* p, const GlobalHistArgs& a, hipStr
     return launch_global_histogram_u64(p->radix_bits, static_cast<int>(blocks), a, s);
 }
 
-static int launch_ghist_scan(const mrs_plan* p, uint32_t num_passes, hipStream_t s)
+// `n` != 0: the scan also fills the plan's pass_plan words (which passes need not run).
+static int launch_ghist_scan(const mrs_plan* p, uint32_t num_passes, uint32_t n, hipStream_t s)
 {
     const unsigned threads = p->radix < 64 ? 64 : p->radix;
+    uint32_t* pass_plan = n ? p->control->pass_plan : nullptr;
     if (p->radix_bits == 4)
-        hipLaunchKernelGGL(global_histogram_scan_kernel<4>, dim3(num_passes), dim3(threads), 0, s, p->control->ghist);
+        hipLaunchKernelGGL(global_histogram_scan_kernel<4>, dim3(num_passes), dim3(threads), 0, s, p->control->ghist,
+                           pass_plan, n, num_passes);
     else
-        hipLaunchKernelGGL(global_histogram_scan_kernel<8>, dim3(num_passes), dim3(threads), 0, s, p->control->ghist);
+        hipLaunchKernelGGL(global_histogram_scan_kernel<8>, dim3(num_passes), dim3(threads), 0, s, p->control->ghist,
+                           pass_plan, n, num_passes);
     MRS_CHECK_LAUNCH("global_histogram_scan_kernel");
     return MRS_OK;
 }
@@ -472,6 +476,10 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
         if (int rc = launch_small_sort(plan->desc.key_words, plan->radix_bits, a, s)) return rc;
         return mark(plan, "small_sort", s);
     }
+    // 64-bit keys: passes whose digit is the same for every key are left out on the device
+    // (see global_histogram_scan_kernel; MRS_NO_PASS_SKIP=1: A/B aid)
+    static const bool no_pass_skip = std::getenv("MRS_NO_PASS_SKIP") != nullptr;
+    const bool skip_passes = plan->desc.algo == MRS_ALGO_ONESWEEP && plan->desc.key_words == 2 && !no_pass_skip;
     if (plan->desc.algo == MRS_ALGO_ONESWEEP) {
         const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
         const size_t zero = kControlBytes + align_up(region * plan->num_passes, 256);
@@ -492,7 +500,7 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
             if (int rc = launch_global_hist(plan, h, s)) return rc;
             if (int rc = mark(plan, "global_histogram", s)) return rc;
         }
-        if (int rc = launch_ghist_scan(plan, plan->num_passes, s)) return rc;
+        if (int rc = launch_ghist_scan(plan, plan->num_passes, skip_passes ? n32 : 0, s)) return rc;
         if (int rc = mark(plan, "histogram_scan", s)) return rc;
     }
 
@@ -526,6 +534,7 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
             a.tile_counter = plan->control->tile_counter[pass];
             a.xcd_block = xcd_block_tiles(plan->ctx);
             a.error_flag = plan->error_flag;
+            a.pass_plan = skip_passes ? plan->control->pass_plan + pass : nullptr;
 #ifdef MRS_STAMPS
             static const uint32_t stamp_pass = std::getenv("MRS_STAMP_PASS") ? std::atoi(std::getenv("MRS_STAMP_PASS")) : 1;
             a.stamps = pass == stamp_pass ? g_debug_stamps : nullptr;
@@ -741,7 +750,7 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
         MRS_HIP_TRY(hipMemsetAsync(part_counts_dev, 0, 16 * sizeof(uint32_t), s));
         MRS_HIP_TRY(hipMemcpyAsync(part_counts_dev, plan->control->ghist, have, hipMemcpyDeviceToDevice, s));
     }
-    if (int rc = launch_ghist_scan(plan, 1, s)) return rc;
+    if (int rc = launch_ghist_scan(plan, 1, 0, s)) return rc;
     PassArgs a{};
     a.keys_in = keys_in;
     a.vals_in = vals_in;

@@ -58,6 +58,11 @@ struct PassArgs {
     uint32_t* tile_counter;      // ticket dispensers of this pass: kTicketLists counters
     uint32_t xcd_block;          // tiles per ticket block (see draw_tile in mrs_radix_pass.hpp); 0 = one list
     uint32_t* error_flag;
+    // optional, 64-bit keys: one word written by global_histogram_scan_kernel for this pass.
+    // Bit 0: every key has the same digit, the pass would move nothing: do not run.  Bit 1: an
+    // odd number of earlier passes did not run, so the input is where the output was expected:
+    // exchange the roles of the two buffer pairs.
+    const uint32_t* pass_plan;
     uint32_t atomic_rank;        // host side only: rank with returning LDS atomics (kRankAtomic)
 #ifdef MRS_STAMPS
     unsigned long long* stamps;  // diagnostic builds only: [num_tiles][8] phase clocks
@@ -69,6 +74,7 @@ struct PassArgs {
 struct OnesweepControl {
     uint32_t ghist[kMaxPasses * kMaxRadix];  // global digit histograms, then their scans
     uint32_t tile_counter[kMaxPasses][kTicketLists];
+    uint32_t pass_plan[kMaxPasses];  // see PassArgs::pass_plan; 0 = run as scheduled
 };
 static_assert(sizeof(OnesweepControl) % 16 == 0, "memset block must be a multiple of 16 bytes");
 

@@ -150,16 +150,39 @@ __global__ __launch_bounds__(256) void global_histogram_kernel(const GlobalHistA
 
 // In-place exclusive scan of each pass's global histogram; one workgroup of
 // RADIX threads (rounded up to a wave) per pass.
+//
+// With `pass_plan` the workgroup of pass p also decides whether its pass runs.  A pass whose
+// digit is the same for all n keys (the zero high bytes of a short code) is a stable identity
+// and can be left out, but the ping-pong schedule and the side the caller was promised
+// (src/main.rs:819-823) are fixed on the host before any key is read.  So passes are left out
+// in pairs: if the number of such passes is odd, the last of them runs after all (it costs what
+// a copy to the promised side would), and every pass that runs learns from bit 1 whether an odd
+// number of passes before it was left out, i.e. whether its input lies in its output buffers.
+//
+// The other workgroups scan their histograms in place while this one looks at them.  The test
+// "every word is 0 or n" gives the same answer on counts, on their exclusive scan and on any
+// mixture of the two: with one occupied bin both are 0 or n everywhere, and at the second
+// occupied bin of any other histogram the count and the scan both lie strictly between 0 and n.
 template <int BITS>
-__global__ void global_histogram_scan_kernel(uint32_t* ghist)
+__global__ void global_histogram_scan_kernel(uint32_t* ghist, uint32_t* pass_plan, uint32_t n, uint32_t num_passes)
 {
     constexpr int RADIX = 1 << BITS;
     __shared__ uint32_t s[RADIX];
+    __shared__ uint32_t s_spread[kMaxPasses];  // pass q has keys in more than one bin
     uint32_t* h = ghist + static_cast<size_t>(blockIdx.x) * RADIX;
     const int t = threadIdx.x;
     const uint32_t own = t < RADIX ? h[t] : 0;
     if (t < RADIX) s[t] = own;
+    if (t < kMaxPasses) s_spread[t] = 0;
     __syncthreads();
+    if (pass_plan && t < RADIX) {
+        for (uint32_t q = 0; q < num_passes; ++q) {
+            const uint32_t v = q == blockIdx.x ? own
+                                               : __hip_atomic_load(ghist + q * RADIX + t, __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 0 && v != n) s_spread[q] = 1;  // benign race: every writer stores 1
+        }
+    }
     for (int o = 1; o < RADIX; o <<= 1) {
         uint32_t y = 0;
         if (t < RADIX && t >= o) y = s[t - o];
@@ -168,6 +191,17 @@ __global__ void global_histogram_scan_kernel(uint32_t* ghist)
         __syncthreads();
     }
     if (t < RADIX) h[t] = s[t] - own;
+    if (pass_plan && t == 0) {
+        const uint32_t p = blockIdx.x;
+        uint32_t identities = 0, last = 0;
+        for (uint32_t q = 0; q < num_passes; ++q)
+            if (!s_spread[q]) { ++identities; last = q; }
+        uint32_t left_out_before = 0;
+        for (uint32_t q = 0; q < p; ++q)
+            if (!s_spread[q] && !((identities & 1u) && q == last)) ++left_out_before;
+        const uint32_t leave_out = !s_spread[p] && !((identities & 1u) && p == last);
+        pass_plan[p] = leave_out | ((left_out_before & 1u) << 1);
+    }
 }
 
 }  // namespace mrs

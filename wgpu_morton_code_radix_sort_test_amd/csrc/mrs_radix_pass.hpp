@@ -586,12 +586,9 @@ __device__ __forceinline__ uint32_t die_local_tile(uint32_t wg, uint32_t num_til
 constexpr int pass_min_waves_per_simd(int threads, int kpt) { return threads == 512 && kpt == 32 ? 4 : 1; }
 
 template <int MODE, int RANK, bool MAP, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
-__global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) void digit_pass_kernel(const PassArgs a)
+__device__ __forceinline__ void run_digit_pass(const PassArgs& a, PassShared<BITS, THREADS, KPT, KeyT, ValT>& sh)
 {
     using S = PassShared<BITS, THREADS, KPT, KeyT, ValT>;
-    static_assert(THREADS % 64 == 0 && THREADS >= S::RADIX, "one thread per digit is required");
-    __shared__ S sh;
-
     const int tid = threadIdx.x;
 #ifdef MRS_STAMPS
     const unsigned long long t_begin = wall_clock64();
@@ -614,14 +611,37 @@ __global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) voi
 #endif
     MRS_STAMP(1);
 
-    const unsigned long long tile_base = static_cast<unsigned long long>(tile) * S::TILE;
-    const uint32_t tile_valid = (a.n - tile_base) < static_cast<unsigned long long>(S::TILE)
-                                    ? static_cast<uint32_t>(a.n - tile_base)
-                                    : S::TILE;
-    if (tile_valid == S::TILE)
-        process_tile<MODE, RANK, MAP, true, StatusT>(a, sh, tile, tile_valid);
+    // tile < num_tiles, so tile * TILE < n < 2^32.  Kept in 32 bits and without a select on
+    // purpose: ROCm 7.2's compiler turned `(u64 difference < TILE) ? difference : TILE` into a
+    // vector compare followed by s_cselect_b32 on a stale SCC (tools/check_scc.py finds these).
+    const uint32_t remaining = a.n - tile * static_cast<uint32_t>(S::TILE);
+    if (remaining >= static_cast<uint32_t>(S::TILE))
+        process_tile<MODE, RANK, MAP, true, StatusT>(a, sh, tile, S::TILE);
     else
-        process_tile<MODE, RANK, MAP, false, StatusT>(a, sh, tile, tile_valid);
+        process_tile<MODE, RANK, MAP, false, StatusT>(a, sh, tile, remaining);
+}
+
+template <int MODE, int RANK, bool MAP, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
+__global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) void digit_pass_kernel(const PassArgs a)
+{
+    using S = PassShared<BITS, THREADS, KPT, KeyT, ValT>;
+    static_assert(THREADS % 64 == 0 && THREADS >= S::RADIX, "one thread per digit is required");
+    __shared__ S sh;
+    if constexpr (MODE == kModeOnesweep && !MAP && sizeof(KeyT) == 8) {
+        // Sorts of 64-bit keys: the device decided after the histograms which passes run
+        // and on which side their input lies (PassArgs::pass_plan).  The word is uniform.
+        const uint32_t plan = a.pass_plan ? *a.pass_plan : 0u;
+        if (plan & 1u) return;  // nothing to move; no ticket is drawn, no status word written
+        const bool other_side = (plan & 2u) != 0u;
+        PassArgs b = a;
+        b.keys_in = other_side ? a.keys_out : a.keys_in;
+        b.vals_in = other_side ? a.vals_out : a.vals_in;
+        b.keys_out = other_side ? const_cast<void*>(a.keys_in) : a.keys_out;
+        b.vals_out = other_side ? const_cast<void*>(a.vals_in) : a.vals_out;
+        run_digit_pass<MODE, RANK, MAP, StatusT>(b, sh);
+    } else {
+        run_digit_pass<MODE, RANK, MAP, StatusT>(a, sh);
+    }
 }
 
 template <int MODE, int RANK, bool MAP, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
