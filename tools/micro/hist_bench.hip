@@ -53,6 +53,39 @@ __global__ __launch_bounds__(256) void hist_v(const uint4* __restrict__ keys, si
     }
 }
 
+// V5: R copies of every counter, copy = lane % R, so the lanes of one atomic instruction spread
+// over the LDS banks whatever their digits are (R = 32: no two lanes of a half-wave share a bank)
+template <int UNROLL, int R, int THREADS>
+__global__ __launch_bounds__(THREADS) void hist_banked(const uint4* __restrict__ keys, size_t nvec, uint32_t* ghist) {
+    extern __shared__ uint32_t sb[];
+    for (int j = threadIdx.x; j < 1024 * R; j += THREADS) sb[j] = 0;
+    __syncthreads();
+    const int copy = threadIdx.x & (R - 1);
+    auto count = [&](uint32_t k) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t d = (k >> (8 * p)) & 0xFFu;
+            atomicAdd(&sb[(p * 256 + d) * R + copy], 1u);
+        }
+    };
+    const size_t stride = (size_t)gridDim.x * THREADS;
+    size_t v = (size_t)blockIdx.x * THREADS + threadIdx.x;
+    for (; v + (UNROLL - 1) * stride < nvec; v += UNROLL * stride) {
+        uint4 x[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) x[u] = keys[v + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { count(x[u].x); count(x[u].y); count(x[u].z); count(x[u].w); }
+    }
+    for (; v < nvec; v += stride) { uint4 x = keys[v]; count(x.x); count(x.y); count(x.z); count(x.w); }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 1024; j += THREADS) {
+        uint32_t c = 0;
+        for (int r = 0; r < R; ++r) c += sb[j * R + ((r + j) & (R - 1))];
+        if (c) atomicAdd(&ghist[j], c);
+    }
+}
+
 // V6: load only, xor-reduce (speed of light for this access pattern)
 template <int UNROLL>
 __global__ __launch_bounds__(256) void load_only(const uint4* __restrict__ keys, size_t nvec, uint32_t* ghist) {
@@ -98,7 +131,7 @@ int main() {
         printf("%-28s grid %5d  %.3f ms  %.0f GB/s  %s\n", name, grid, ms, n * 4 / ms / 1e6, ok ? "ok" : "MISMATCH");
         fflush(stdout);
     };
-    for (int grid : {1024, 2048, 4096}) {
+    for (int grid : {4096}) {
         run("plain u1", hist_v<1, 1, false>, grid);
         run("plain u2", hist_v<2, 1, false>, grid);
         run("plain u4", hist_v<4, 1, false>, grid);
@@ -107,6 +140,29 @@ int main() {
         run("wave-private u2", hist_v<2, 4, false>, grid);
         run("wave-private u4 check", hist_v<4, 4, true>, grid);
         run("2-private u4", hist_v<4, 2, false>, grid);
+    }
+    auto run_banked = [&](const char* name, auto kern, int grid, int threads, int copies) {
+        const size_t lds = 4096 * (size_t)copies;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipMemset(g, 0, 4096));
+        float ms = time_it([&] { kern<<<grid, threads, lds>>>(kv, nvec, g); });
+        CK(hipMemset(g, 0, 4096)); kern<<<grid, threads, lds>>>(kv, nvec, g); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), g, 4096, hipMemcpyDeviceToHost));
+        printf("%-28s grid %5d  %.3f ms  %.0f GB/s  %s\n", name, grid, ms, n * 4 / ms / 1e6, ref == got ? "ok" : "MISMATCH");
+        fflush(stdout);
+    };
+    for (int grid : {256, 512}) {
+        run_banked("banked R32 1024thr u2", hist_banked<2, 32, 1024>, grid, 1024, 32);
+        run_banked("banked R32 1024thr u4", hist_banked<4, 32, 1024>, grid, 1024, 32);
+    }
+    for (int grid : {512, 1024}) {
+        run_banked("banked R16 512thr u2", hist_banked<2, 16, 512>, grid, 512, 16);
+        run_banked("banked R16 512thr u4", hist_banked<4, 16, 512>, grid, 512, 16);
+        run_banked("banked R16 1024thr u4", hist_banked<4, 16, 1024>, grid / 2, 1024, 16);
+    }
+    for (int grid : {1024, 2048}) {
+        run_banked("banked R8 256thr u4", hist_banked<4, 8, 256>, grid, 256, 8);
+        run_banked("banked R4 256thr u4", hist_banked<4, 4, 256>, grid, 256, 4);
     }
     for (int grid : {2048, 4096}) {
         float ms = time_it([&] { load_only<4><<<grid, 256>>>(kv, nvec, g); });

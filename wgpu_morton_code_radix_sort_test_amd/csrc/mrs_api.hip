@@ -35,8 +35,8 @@ int launch_block_histogram_u32(int bits, uint32_t n, const void* keys, uint32_t 
                                uint32_t shift, uint32_t mask, uint32_t* hist, hipStream_t s);
 int launch_block_histogram_u64(int bits, uint32_t n, const void* keys, uint32_t tile_items, uint32_t num_tiles,
                                uint32_t shift, uint32_t mask, uint32_t* hist, hipStream_t s);
-int launch_global_histogram_u32(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
-int launch_global_histogram_u64(int bits, int grid, const GlobalHistArgs& a, hipStream_t s);
+int launch_global_histogram_u32(int bits, int grid, int grid_banked, const GlobalHistArgs& a, hipStream_t s);
+int launch_global_histogram_u64(int bits, int grid, int grid_banked, const GlobalHistArgs& a, hipStream_t s);
 int probe_lds_atomic_order(bool* in_order);
 int probe_die_ids(bool* all_dies);
 // mrs_morton.hip
@@ -154,8 +154,22 @@ static int launch_global_hist(const mrs_plan* p, const GlobalHistArgs& a, hipStr
     const uint64_t cap = static_cast<uint64_t>(p->ctx->num_cus) * per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
-    if (p->desc.key_words == 1) return launch_global_histogram_u32(p->radix_bits, static_cast<int>(blocks), a, s);
-    return launch_global_histogram_u64(p->radix_bits, static_cast<int>(blocks), a, s);
+    // The sorts use the kernel with bank-spread counters: 1024 threads and 64 KiB of LDS per
+    // workgroup, two per compute unit, at least 4 vectors per thread (MRS_HIST_PLAIN=1: A/B aid;
+    // MRS_HIST_BANKED_PER_CU: tuning aid).
+    static const bool plain = std::getenv("MRS_HIST_PLAIN") != nullptr;
+    static const uint64_t banked_per_cu =
+        std::getenv("MRS_HIST_BANKED_PER_CU") ? std::atoi(std::getenv("MRS_HIST_BANKED_PER_CU")) : 2;
+    uint64_t banked = 0;
+    if (!plain && !a.digit_map) {
+        banked = (a.n / vec + 1024 * 4 - 1) / (1024 * 4);
+        const uint64_t banked_cap = static_cast<uint64_t>(p->ctx->num_cus) * banked_per_cu;
+        if (banked > banked_cap) banked = banked_cap;
+        if (banked == 0) banked = 1;
+    }
+    if (p->desc.key_words == 1)
+        return launch_global_histogram_u32(p->radix_bits, static_cast<int>(blocks), static_cast<int>(banked), a, s);
+    return launch_global_histogram_u64(p->radix_bits, static_cast<int>(blocks), static_cast<int>(banked), a, s);
 }
 
 // `n` != 0: the scan also fills the plan's pass_plan words (which passes need not run).

@@ -148,6 +148,84 @@ __global__ __launch_bounds__(256) void global_histogram_kernel(const GlobalHistA
     }
 }
 
+// The same histograms with every counter kept in R copies, copy = lane % R.  The cost of an
+// LDS atomic instruction is set by its worst bank: with one counter per digit, 64 random
+// digits put 5 or 6 lanes on some bank (and equal digits put all 64 on one word); with the
+// copies interleaved, the lanes of one instruction spread over R consecutive banks whatever
+// their digits are.  2^28 keys x 4 digits: 0.18 ms against 0.29-0.34 ms for the kernel
+// above (tools/micro/hist_bench.hip), which is the rate of a read-only sweep.
+template <int BITS, typename KeyT>
+struct BankedHistogram {
+    static constexpr int RADIX = 1 << BITS;
+    static constexpr int MAXP = (sizeof(KeyT) * 8 + BITS - 1) / BITS;
+    static constexpr int COUNTERS = MAXP * RADIX;
+    static constexpr int WORDS = 16384;  // 64 KiB: two workgroups per compute unit
+    static constexpr int R = WORDS / COUNTERS > 32 ? 32 : WORDS / COUNTERS;
+    static constexpr int THREADS = 1024;
+    static_assert(R >= 4 && (R & (R - 1)) == 0, "copies must be a power of two");
+};
+
+// ALL: a.num_passes equals MAXP (the usual case), so no pass needs a test.
+template <int BITS, typename KeyT, bool ALL>
+__global__ __launch_bounds__(1024) void global_histogram_banked_kernel(const GlobalHistArgs a)
+{
+    using B = BankedHistogram<BITS, KeyT>;
+    constexpr int RADIX = B::RADIX, MAXP = B::MAXP, R = B::R, THREADS = B::THREADS;
+    constexpr int VEC = 16 / sizeof(KeyT);
+    constexpr int UNROLL = 4;  // vectors in flight per thread
+    __shared__ uint32_t s_hist[B::COUNTERS * R];
+    for (int j = threadIdx.x; j < B::COUNTERS * R; j += THREADS) s_hist[j] = 0;
+    __syncthreads();
+
+    const KeyT* __restrict__ keys = static_cast<const KeyT*>(a.keys);
+    const uint32_t copy = threadIdx.x & (R - 1);
+    auto count = [&](KeyT k) {
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            if (ALL || p < static_cast<int>(a.num_passes)) {
+                const uint32_t shift = a.begin_bit + p * BITS;
+                const uint32_t width = a.end_bit - shift < static_cast<uint32_t>(BITS) ? a.end_bit - shift : BITS;
+                uint32_t d;
+                if constexpr (sizeof(KeyT) == 4)
+                    d = __builtin_amdgcn_ubfe(k, shift, width);
+                else
+                    d = static_cast<uint32_t>(k >> shift) & ((1u << width) - 1u);
+                atomicAdd(&s_hist[(p * RADIX + d) * R + copy], 1u);
+            }
+        }
+    };
+    using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
+    auto count_vec = [&](const VecT& x) {
+        count(x.x);
+        count(x.y);
+        if constexpr (sizeof(KeyT) == 4) {
+            count(x.z);
+            count(x.w);
+        }
+    };
+    const unsigned long long nvec = a.n / VEC;
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * THREADS;
+    const VecT* __restrict__ vkeys = reinterpret_cast<const VecT*>(keys);
+    unsigned long long v = static_cast<unsigned long long>(blockIdx.x) * THREADS + threadIdx.x;
+    for (; v + (UNROLL - 1) * stride < nvec; v += UNROLL * stride) {
+        VecT x[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) x[u] = vkeys[v + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) count_vec(x[u]);
+    }
+    for (; v < nvec; v += stride) count_vec(vkeys[v]);
+    // tail (n not a multiple of the vector width): first lanes of block 0
+    if (blockIdx.x == 0 && nvec * VEC + threadIdx.x < a.n) count(keys[nvec * VEC + threadIdx.x]);
+    __syncthreads();
+    for (int j = threadIdx.x; j < static_cast<int>(a.num_passes) * RADIX; j += THREADS) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) c += s_hist[j * R + ((r + j) & (R - 1))];  // rotated: threads on distinct banks
+        if (c) atomicAdd(&a.ghist[j], c);
+    }
+}
+
 // In-place exclusive scan of each pass's global histogram; one workgroup of
 // RADIX threads (rounded up to a wave) per pass.
 //

@@ -17,8 +17,8 @@ int launch_block_histogram_u64(int bits, uint32_t n, const void* keys, uint32_t 
 {
     return launch_block_histogram_key<unsigned long long>(bits, n, keys, tile_items, num_tiles, shift, mask, hist, s);
 }
-int launch_global_histogram_u64(int bits, int grid, const GlobalHistArgs& a, hipStream_t s)
+int launch_global_histogram_u64(int bits, int grid, int grid_banked, const GlobalHistArgs& a, hipStream_t s)
 {
-    return launch_global_histogram_key<unsigned long long>(bits, grid, a, s);
+    return launch_global_histogram_key<unsigned long long>(bits, grid, grid_banked, a, s);
 }
 }  // namespace mrs
