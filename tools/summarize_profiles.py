@@ -55,7 +55,7 @@ def main():
     fetch = counter_means(os.path.join(ROOT, args.fetch_dir, "**", "*counter_collection.csv"), "FETCH_SIZE")
     write = counter_means(os.path.join(ROOT, args.write_dir, "**", "*counter_collection.csv"), "WRITE_SIZE")
     if fetch and write:
-        enc_f, hist_f = pick(fetch, "morton_encode30"), pick(fetch, "global_histogram_kernel")
+        enc_f, hist_f = pick(fetch, "morton_encode30"), pick(fetch, "global_histogram_banked_kernel") or pick(fetch, "global_histogram_kernel")
         enc_w = pick(write, "morton_encode30")
         cal_enc = 12.0 * n / (enc_f * 1024.0)
         cal_hist = 4.0 * n / (hist_f * 1024.0)
