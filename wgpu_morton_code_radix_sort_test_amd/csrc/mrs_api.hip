@@ -161,7 +161,7 @@ static int launch_global_hist(const mrs_plan* p, const GlobalHistArgs& a, hipStr
     static const uint64_t banked_per_cu =
         std::getenv("MRS_HIST_BANKED_PER_CU") ? std::atoi(std::getenv("MRS_HIST_BANKED_PER_CU")) : 2;
     uint64_t banked = 0;
-    if (!plain && !a.digit_map) {
+    if (!plain) {
         banked = (a.n / vec + 1024 * 4 - 1) / (1024 * 4);
         const uint64_t banked_cap = static_cast<uint64_t>(p->ctx->num_cus) * banked_per_cu;
         if (banked > banked_cap) banked = banked_cap;

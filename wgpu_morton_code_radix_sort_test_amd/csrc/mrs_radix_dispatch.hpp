@@ -89,13 +89,13 @@ int launch_block_histogram_key(int bits, uint32_t n, const void* keys, uint32_t 
     return MRS_OK;
 }
 
-// grid_banked > 0 selects global_histogram_banked_kernel (not for mapped digits).
+// grid_banked > 0 selects global_histogram_banked_kernel.
 template <typename KeyT>
 int launch_global_histogram_key(int bits, int grid, int grid_banked, const GlobalHistArgs& a, hipStream_t s)
 {
-    if (grid_banked > 0 && !a.digit_map) {
-        const bool all4 = a.num_passes == static_cast<uint32_t>(BankedHistogram<4, KeyT>::MAXP);
-        const bool all8 = a.num_passes == static_cast<uint32_t>(BankedHistogram<8, KeyT>::MAXP);
+    if (grid_banked > 0) {
+        const bool all4 = !a.digit_map && a.num_passes == static_cast<uint32_t>(BankedHistogram<4, KeyT>::MAXP);
+        const bool all8 = !a.digit_map && a.num_passes == static_cast<uint32_t>(BankedHistogram<8, KeyT>::MAXP);
         const dim3 g(grid_banked), b(1024);
         if (bits == 4 && all4)
             hipLaunchKernelGGL((global_histogram_banked_kernel<4, KeyT, true>), g, b, 0, s, a);

@@ -180,6 +180,15 @@ __global__ __launch_bounds__(1024) void global_histogram_banked_kernel(const Glo
     const KeyT* __restrict__ keys = static_cast<const KeyT*>(a.keys);
     const uint32_t copy = threadIdx.x & (R - 1);
     auto count = [&](KeyT k) {
+        if constexpr (!ALL) {
+            // partition mode: one pass over at most 16 mapped digits, where the copies matter
+            // most (a wave's 64 lanes would otherwise queue on a handful of words)
+            if (a.digit_map) {
+                const uint32_t d = a.digit_map[static_cast<uint32_t>(k >> a.begin_bit) & a.map_mask];
+                atomicAdd(&s_hist[d * R + copy], 1u);
+                return;
+            }
+        }
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
             if (ALL || p < static_cast<int>(a.num_passes)) {
