@@ -164,6 +164,18 @@ int main() {
         run_banked("banked R8 256thr u4", hist_banked<4, 8, 256>, grid, 256, 8);
         run_banked("banked R4 256thr u4", hist_banked<4, 4, 256>, grid, 256, 4);
     }
+    {   // the same kernel over three different inputs in turn: nothing of the previous sweep is cached
+        uint32_t* k3[3] = {k, nullptr, nullptr};
+        for (int i = 1; i < 3; ++i) { CK(hipMalloc(&k3[i], n * 4)); fill<<<4096, 256>>>(k3[i], n); }
+        CK(hipDeviceSynchronize());
+        auto kern = hist_banked<4, 16, 1024>;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        int turn = 0;
+        float ms = time_it([&] { kern<<<512, 1024, 65536>>>((const uint4*)k3[turn++ % 3], nvec, g); }, 9);
+        printf("banked R16 1024thr u4 grid 512, rotating inputs  %.3f ms\n", ms);
+        ms = time_it([&] { kern<<<512, 1024, 65536>>>((const uint4*)k3[0], nvec, g); }, 9);
+        printf("banked R16 1024thr u4 grid 512, same input       %.3f ms\n", ms);
+    }
     for (int grid : {2048, 4096}) {
         float ms = time_it([&] { load_only<4><<<grid, 256>>>(kv, nvec, g); });
         printf("load only u4 grid %d  %.3f ms %.0f GB/s\n", grid, ms, n * 4 / ms / 1e6);
