@@ -122,6 +122,14 @@ int mrs_plan_get_info(const mrs_plan* plan, mrs_plan_info* info);
  * kernel gave up waiting for a predecessor tile since the last check.  For
  * tests and harnesses; not needed on the hot path. */
 int mrs_plan_check(mrs_plan* plan, void* stream);
+/* Synchronises `stream` and reports, for the most recent mrs_sort_pairs call on
+ * an MRS_ALGO_ONESWEEP plan, which passes the device left out: bit p of
+ * *left_out_mask is set when pass p did not run (64-bit keys whose digit p is
+ * the same for every key; see mrs_sort_pairs).  0 for other plans, for 32-bit
+ * keys and for inputs sorted by the one-workgroup path.  For tests and
+ * harnesses (the reference has no counterpart: it always runs every pass,
+ * src/main.rs:594-665). */
+int mrs_plan_get_passes_left_out(mrs_plan* plan, void* stream, uint32_t* left_out_mask);
 
 /* Measurement hook (the reference has no timers; its passes are named for an
  * external profiler, src/main.rs:583-662).  With timing enabled, mrs_sort_pairs

@@ -54,6 +54,7 @@ extern "C" {
     pub fn mrs_plan_destroy(plan: *mut mrs_plan) -> c_int;
     pub fn mrs_plan_get_info(plan: *const mrs_plan, info: *mut PlanInfo) -> c_int;
     pub fn mrs_plan_check(plan: *mut mrs_plan, stream: *mut c_void) -> c_int;
+    pub fn mrs_plan_get_passes_left_out(plan: *mut mrs_plan, stream: *mut c_void, left_out_mask: *mut u32) -> c_int;
     pub fn mrs_plan_set_timing(plan: *mut mrs_plan, enable: c_int) -> c_int;
     pub fn mrs_plan_get_timings(plan: *mut mrs_plan, cap: c_int, ms_out: *mut f32, labels_out: *mut c_char,
                                 count_out: *mut c_int) -> c_int;

@@ -414,6 +414,18 @@ def test_u64_passes_left_out(ctx, oracle, mrs, monkeypatch, lo_mask, hi_mask, pa
         rk, rv = oracle.stable_sort_pairs(keys, vals, n, 2, payload_words, begin, end)
         assert np.array_equal(ko, rk) and np.array_equal(vo, rv), (bits, begin, end)
         assert in_b == ((-(-(end - begin) // bits)) % 2 == 1)
+    # which passes the device reports as left out: the constant bytes, minus the last of them
+    # when their number is odd
+    constant = [p for p in range(8) if (((hi_mask << 32) | lo_mask) >> (8 * p)) & 0xFF == 0]
+    if len(constant) % 2:
+        constant = constant[:-1]
+    plan = mrs.SortPlan(ctx, n, key_words=2, payload_bytes=4 * payload_words)
+    ka, va = to_dev(keys, ctx.device), to_dev(vals, ctx.device)
+    plan.sort_pairs(ka, va, torch.empty_like(ka), torch.empty_like(va))
+    assert plan.passes_left_out() == sum(1 << p for p in constant)
+    plan.sort_pairs(ka[: 2 * 100], va[: 100 * payload_words], torch.empty_like(ka), torch.empty_like(va), n=100)
+    assert plan.passes_left_out() == 0  # the one-workgroup path keeps no record
+    plan.close()
     monkeypatch.setenv("MRS_NO_SMALL_SORT", "1")
     m = 777
     ko, vo, _ = gpu_sort(ctx, mrs, keys[: 2 * m], vals[: m * payload_words], m, 2, payload_words, 8, 0, 64, mrs.ALGO_ONESWEEP)

@@ -311,3 +311,10 @@ class SortPlan:
     def check(self, stream=None):
         """Synchronises and raises MrsError if a look-back timed out on the device."""
         _lib.check(self.lib.mrs_plan_check(self._h, _stream(stream)))
+
+    def passes_left_out(self, stream=None):
+        """Synchronises; bit p is set if pass p of the last sort_pairs did not run on the device
+        (64-bit keys whose digit p is the same for every key)."""
+        mask = ctypes.c_uint32(0)
+        _lib.check(self.lib.mrs_plan_get_passes_left_out(self._h, _stream(stream), ctypes.byref(mask)))
+        return mask.value

@@ -438,6 +438,21 @@ extern "C" int mrs_plan_check(mrs_plan* plan, void* stream)
     return MRS_OK;
 }
 
+extern "C" int mrs_plan_get_passes_left_out(mrs_plan* plan, void* stream, uint32_t* left_out_mask)
+{
+    clear_error();
+    if (!plan || !left_out_mask) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_get_passes_left_out: null argument");
+    if (int rc = check_device(plan->ctx, "mrs_plan_get_passes_left_out")) return rc;
+    *left_out_mask = 0;
+    MRS_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (!plan->pass_plan_live) return MRS_OK;
+    uint32_t words[kMaxPasses];
+    MRS_HIP_TRY(hipMemcpy(words, plan->control->pass_plan, sizeof words, hipMemcpyDeviceToHost));
+    for (uint32_t p = 0; p < plan->num_passes; ++p)
+        if (words[p] & 1u) *left_out_mask |= 1u << p;
+    return MRS_OK;
+}
+
 static int check_pair_buffers(const mrs_plan* plan, const void* ka, const void* va, const void* kb, const void* vb,
                               const char* who)
 {
@@ -471,6 +486,7 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
     // histograms left by mrs_morton_encode30_for_sort for exactly these keys?
     const bool primed = plan->primed_keys == keys_a && plan->primed_n == n && plan->desc.algo == MRS_ALGO_ONESWEEP;
     plan->primed_keys = nullptr;
+    plan->pass_plan_live = false;
     plan->num_marks = 0;
     if (int rc = mark(plan, "start", s)) return rc;
     // Small inputs: the whole sort in one launch of one workgroup (MRS_NO_SMALL_SORT=1: A/B aid).
@@ -494,6 +510,7 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
     // (see global_histogram_scan_kernel; MRS_NO_PASS_SKIP=1: A/B aid)
     static const bool no_pass_skip = std::getenv("MRS_NO_PASS_SKIP") != nullptr;
     const bool skip_passes = plan->desc.algo == MRS_ALGO_ONESWEEP && plan->desc.key_words == 2 && !no_pass_skip;
+    plan->pass_plan_live = skip_passes;
     if (plan->desc.algo == MRS_ALGO_ONESWEEP) {
         const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
         const size_t zero = kControlBytes + align_up(region * plan->num_passes, 256);

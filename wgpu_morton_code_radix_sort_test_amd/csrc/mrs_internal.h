@@ -131,6 +131,8 @@ struct mrs_plan {
     uint32_t status_word_bytes;  // 4 below 2^30 elements, else 8
     char* zero_begin;            // control block + status regions: cleared by one memset per call
     uint32_t* error_flag;        // sticky device word
+    // the last mrs_sort_pairs call let the device decide which passes run (control->pass_plan is its record)
+    bool pass_plan_live;
     // mrs_morton_encode30_for_sort left the digit histograms of these keys in `control`
     const void* primed_keys;
     uint64_t primed_n;
