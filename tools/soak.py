@@ -12,14 +12,58 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wgpu_morton_code_radix_sort_test_amd as mrs  # noqa: E402
 
 
+HI_MASKS = [0xFFFFFFFF, 0x0000FFFF, 0x000000FF, 0x00000000, 0x00FF00FF, 0xFF000000, 0x000F0000, 0x0FFFFFFF]
+
+
+def soak_u64(ctx, n, args):
+    plan = mrs.SortPlan(ctx, n, key_words=2, payload_bytes=4, tile_items=args.tile_items)
+    kb = torch.empty(2 * n, dtype=torch.int32, device=ctx.device)
+    vb = torch.empty(n, dtype=torch.int32, device=ctx.device)
+    bad = 0
+    for it in range(args.iters):
+        mask = HI_MASKS[it % len(HI_MASKS)]
+        lo = ctx.generate_u32(2000 + it, 1, n)
+        hi = ctx.generate_u32(2000 + it, 2, n) & (mask if mask < (1 << 31) else mask - (1 << 32))
+        if it % 5 == 4:
+            lo &= 0x00FFFF00  # constant low and high byte of the low word as well
+        keys = torch.stack([lo, hi], dim=1).reshape(-1).contiguous()
+        idx = torch.arange(n, dtype=torch.int32, device=ctx.device)
+        ref = (hi.to(torch.int64) << 32) | (lo.to(torch.int64) & 0xFFFFFFFF)
+        del lo, hi
+        in_b = plan.sort_pairs(keys, idx, kb, vb)
+        plan.check()
+        left_out = plan.passes_left_out()
+        ok, ov = (kb, vb) if in_b else (keys, idx)
+        o2 = ok.view(n, 2)
+        k64 = (o2[:, 1].to(torch.int64) << 32) | (o2[:, 0].to(torch.int64) & 0xFFFFFFFF)
+        # compare as unsigned: flip the sign bit
+        ku = k64 ^ (-(1 << 63))
+        sorted_ok = bool((ku[1:] >= ku[:-1]).all())
+        perm_ok = bool((ref[ov.to(torch.int64)] == k64).all())
+        same = k64[1:] == k64[:-1]
+        stable_ok = bool((ov[1:][same] > ov[:-1][same]).all())
+        if not (sorted_ok and perm_ok and stable_ok):
+            bad += 1
+            print(f"iteration {it}: sorted={sorted_ok} permutation={perm_ok} stable={stable_ok}", flush=True)
+        if it % 8 == 7:
+            print(f"{it + 1} sorts checked, {bad} bad (last mask {mask:#x}: passes left out {left_out:#04x})", flush=True)
+    print("SOAK", "FAILED" if bad else "ok", f"({args.iters} sorts of 2^{args.log2n} 64-bit keys + index)")
+    sys.exit(1 if bad else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=28)
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--tile-items", type=int, default=0)
+    ap.add_argument("--u64", action="store_true",
+                    help="64-bit keys + index; the high word is masked differently every iteration, so passes "
+                         "with a constant digit (left out on the device) come and go")
     args = ap.parse_args()
     ctx = mrs.Context(0)
     n = 1 << args.log2n
+    if args.u64:
+        return soak_u64(ctx, n, args)
     plan = mrs.SortPlan(ctx, n, tile_items=args.tile_items)
     kb = torch.empty(n, dtype=torch.int32, device=ctx.device)
     vb = torch.empty(n, dtype=torch.int32, device=ctx.device)
