@@ -606,3 +606,21 @@ def test_errors_are_reported(ctx, mrs):
         plan.sort_pairs(k, k, k, k, n=1000)  # A and B must differ
     with pytest.raises(mrs.MrsError):
         plan.sort_pairs(k, k, k.clone(), k.clone(), n=2000)  # beyond capacity
+
+
+@pytest.mark.parametrize("extra", [[], ["--gather"], ["--algo", "three_kernel"], ["--triangles", "70001", "--vertices", "5000", "--gather"],
+                                   ["--triangles", "70001", "--vertices", "5000", "--passes", "5"]])
+def test_cpp_host_driver(extra):
+    """mrs_run, the compiled counterpart of run_headless (src/main.rs:690-1033): scene, encode,
+    sort, read back, the reference's adjacent-pair check, and equality with std::stable_sort of the
+    encoded input for codes and triangles, carrying the triangles through the passes or gathering them."""
+    import json
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       "wgpu_morton_code_radix_sort_test_amd", "csrc", "mrs_run")
+    assert os.path.exists(exe), "mrs_run is built by `make` in csrc (and by __graft_entry__.build())"
+    r = subprocess.run([exe] + extra, capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["sorted"] and out["matches_stable_sort"] and not out["all_zero"]

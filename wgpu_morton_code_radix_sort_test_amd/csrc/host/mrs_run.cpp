@@ -1,7 +1,9 @@
 // mrs_run: the headless driver (the role of `cargo run` with --cfg radix_sort_readback,
 // src/main.rs:1035-1040): generates the scene, encodes, sorts, reads back and checks.
 //
-//   mrs_run [--triangles N] [--vertices N] [--passes P] [--algo onesweep|three_kernel] [--tile T]
+//   mrs_run [--triangles N] [--vertices N] [--passes P] [--algo onesweep|three_kernel] [--tile T] [--gather]
+//
+// --gather sorts (code, source index) pairs and moves the 16-byte triangles once (mrs_sort_gather).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +22,7 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--vertices")) c.num_vertices = std::strtoul(next("--vertices"), nullptr, 10);
         else if (!std::strcmp(argv[i], "--passes")) c.num_passes = std::strtoul(next("--passes"), nullptr, 10);
         else if (!std::strcmp(argv[i], "--tile")) c.tile_items = std::atoi(next("--tile"));
+        else if (!std::strcmp(argv[i], "--gather")) c.gather_payload = true;
         else if (!std::strcmp(argv[i], "--algo")) {
             const char* a = next("--algo");
             c.algo = std::strcmp(a, "three_kernel") == 0 ? MRS_ALGO_THREE_KERNEL : MRS_ALGO_ONESWEEP;

@@ -137,7 +137,8 @@ std::vector<uint8_t> pack_triangles(const Scene& s)
 
 void Buffers::release()
 {
-    for (void* p : {vertices, indices, indices_2, morton_uniforms, morton_codes, morton_codes_2})
+    for (void* p : {vertices, indices, indices_2, morton_uniforms, morton_codes, morton_codes_2, source_index,
+                    source_index_2})
         if (p) (void)hipFree(p);
     if (plan) mrs_plan_destroy(plan);
     *this = Buffers();
@@ -170,7 +171,7 @@ int run_compute_shaders(mrs_context* ctx, void* stream, const Constants& c, Buff
     mrs_plan_desc d{};
     d.n = n;
     d.key_words = 2;
-    d.payload_bytes = 16;
+    d.payload_bytes = c.gather_payload ? 4 : 16;
     d.digit_bits = static_cast<int32_t>(c.bits_per_pass);
     d.begin_bit = 0;
     d.end_bit = static_cast<int32_t>(c.bits_per_pass * c.num_passes);
@@ -181,9 +182,19 @@ int run_compute_shaders(mrs_context* ctx, void* stream, const Constants& c, Buff
     if (int rc = mrs_morton_encode_lut(ctx, b->morton_uniforms, b->vertices, c.num_vertices, b->indices, n,
                                        static_cast<uint32_t*>(b->morton_codes), stream))
         return rc;
+    if (c.gather_payload) {
+        HOST_HIP_TRY(hipMalloc(&b->source_index, n * 4));
+        HOST_HIP_TRY(hipMalloc(&b->source_index_2, n * 4));
+        b->triangles_in_2 = true;
+        return mrs_sort_gather(b->plan, n, b->morton_codes, b->morton_codes_2, static_cast<uint32_t*>(b->source_index),
+                               static_cast<uint32_t*>(b->source_index_2), b->indices, b->indices_2,
+                               MRS_TRIANGLE_STRIDE, stream, &b->result_in_2);
+    }
     // the pass loop, src/main.rs:594-665
-    return mrs_sort_pairs(b->plan, n, b->morton_codes, b->indices, b->morton_codes_2, b->indices_2, stream,
-                          &b->result_in_2);
+    const int rc = mrs_sort_pairs(b->plan, n, b->morton_codes, b->indices, b->morton_codes_2, b->indices_2, stream,
+                                  &b->result_in_2);
+    b->triangles_in_2 = b->result_in_2 != 0;
+    return rc;
 }
 
 static uint64_t select_bits(uint64_t value, uint32_t i)  // src/main.rs:1042-1051
@@ -212,7 +223,7 @@ int run_headless(const Constants& c, HeadlessResult* res, bool verbose)
     std::vector<uint64_t> keys(n), keys_in(n);
     std::vector<uint32_t> tris(static_cast<size_t>(n) * 4);
     HOST_HIP_TRY(hipMemcpy(keys.data(), b.result_in_2 ? b.morton_codes_2 : b.morton_codes, n * 8ull, hipMemcpyDeviceToHost));
-    HOST_HIP_TRY(hipMemcpy(tris.data(), b.result_in_2 ? b.indices_2 : b.indices, n * 16ull, hipMemcpyDeviceToHost));
+    HOST_HIP_TRY(hipMemcpy(tris.data(), b.triangles_in_2 ? b.indices_2 : b.indices, n * 16ull, hipMemcpyDeviceToHost));
 
     // adjacent-pair check, src/main.rs:831-864
     res->sorted = true;

@@ -22,6 +22,10 @@ struct Constants {
     uint64_t rng_seed = 7;
     int algo = MRS_ALGO_ONESWEEP;
     int tile_items = 0;
+    // false: the 16-byte TriangleIndices travel through every pass, as in the reference
+    // (src/shaders/radix_sort_index.wgsl:281-307).  true: (code, source index) pairs are sorted and the
+    // records move once at the end (mrs_sort_gather), the variant src/types.rs:26-36 anticipates.
+    bool gather_payload = false;
 };
 
 // Stand-in for extended_morton_coder::MortonCodeGenerator (crate not vendored in
@@ -63,8 +67,11 @@ struct Buffers {
     void* morton_uniforms = nullptr;
     void* morton_codes = nullptr;
     void* morton_codes_2 = nullptr;
+    void* source_index = nullptr;    // gather_payload only: u32[n] scratch, ends as the sorted source indices
+    void* source_index_2 = nullptr;
     mrs_plan* plan = nullptr;
-    int result_in_2 = 0;
+    int result_in_2 = 0;      // sorted codes (and, without gather_payload, triangles) are in the _2 buffers
+    bool triangles_in_2 = false;  // where the sorted triangles are
     uint32_t num_triangles = 0;
     void release();
 };
