@@ -372,6 +372,38 @@ def test_single_ticket_list(oracle, mrs):
     ctx2.close()
 
 
+def test_concurrent_sorts_on_two_streams(oracle, mrs):
+    """Two plans sorting at the same time on two streams of one device, with the die-aware tile
+    assignment switched off as documented for this use: with a single ticket list the lowest
+    unfinished tile of either kernel is always held by a running workgroup, so the two kernels can
+    share the compute units in any interleaving."""
+    ctx2 = mrs.Context(0)
+    ctx2.set_attribute(ctx2.ATTR_DIE_AWARE_TICKETS, 0)
+    n = (1 << 21) + 4321
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    plans = [mrs.SortPlan(ctx2, n), mrs.SortPlan(ctx2, n)]
+    host = [(make_keys(oracle, n, 1, "morton30", seed=s), make_vals(oracle, n, 1)) for s in (1, 2)]
+    want = [oracle.stable_sort_pairs(k, v, n, 1, 1, 0, 32) for k, v in host]
+    rounds = 6
+    work = [[(to_dev(k, ctx2.device), to_dev(v, ctx2.device)) for _ in range(rounds)] for k, v in host]
+    scratch = [(torch.empty(n, dtype=torch.int32, device=ctx2.device), torch.empty(n, dtype=torch.int32, device=ctx2.device))
+               for _ in range(2)]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for j in range(2):
+            with torch.cuda.stream(streams[j]):
+                ka, va = work[j][r]
+                assert not plans[j].sort_pairs(ka, va, scratch[j][0], scratch[j][1], stream=streams[j])
+    for j in range(2):
+        plans[j].check(stream=streams[j])
+    torch.cuda.synchronize()
+    for j in range(2):
+        for ka, va in work[j]:
+            assert np.array_equal(to_u32(ka), want[j][0]) and np.array_equal(to_u32(va), want[j][1])
+        plans[j].close()
+    ctx2.close()
+
+
 def test_sort_large_tile_u64_keys(ctx, oracle, mrs):
     """64-bit keys with a 4-byte payload on the 16384-element tile."""
     n = 7 * 16384 + 3
