@@ -597,6 +597,16 @@ def test_bucket_histogram(ctx, oracle):
         counts = ctx.bucket_histogram(to_dev(keys, ctx.device), n, 1, shift, bits).cpu().numpy()
         ref = np.bincount((keys >> np.uint32(shift)) & np.uint32((1 << bits) - 1), minlength=1 << bits)
         assert np.array_equal(counts, ref)
+    # a key array that is not 16-byte aligned (no vector loads), tiny inputs, 64-bit keys
+    dev = to_dev(keys, ctx.device)
+    for first, m in ((1, n - 1), (3, 5), (2, 4099), (0, 1), (0, 3)):
+        counts = ctx.bucket_histogram(dev[first:], m, 1, 20, 12).cpu().numpy()
+        assert np.array_equal(counts, np.bincount(keys[first: first + m] >> np.uint32(20), minlength=4096))
+    k64 = make_keys(oracle, 70001, 2, "random")
+    hi = k64.reshape(-1, 2)[:, 1]
+    for first, m in ((0, 70001), (1, 70000)):
+        counts = ctx.bucket_histogram(to_dev(k64, ctx.device)[2 * first:], m, 2, 52, 12).cpu().numpy()
+        assert np.array_equal(counts, np.bincount(hi[first: first + m] >> np.uint32(20), minlength=4096))
 
 
 @pytest.mark.parametrize("bits_plan", [4, 8])

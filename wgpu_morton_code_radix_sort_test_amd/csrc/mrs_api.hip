@@ -210,19 +210,46 @@ static int mark(mrs_plan* p, const char* label, hipStream_t s)
 static bool misaligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; }
 
 // ---- bucket histogram (multi-GPU split) ---------------------------------------------
+// One LDS atomic per key into `bins` <= 4096 counters; 16-byte loads, four in flight per thread,
+// when the key array is 16-byte aligned (`vectors` = n / keys per vector, else 0).  Few, large
+// workgroups: each ends with up to `bins` 64-bit global atomics on the same words.
 template <typename KeyT>
-__global__ __launch_bounds__(256) void bucket_histogram_kernel(const KeyT* __restrict__ keys, unsigned long long n,
-                                                                uint32_t shift, uint32_t bins,
-                                                                unsigned long long* __restrict__ counts)
+__global__ __launch_bounds__(1024) void bucket_histogram_kernel(const KeyT* __restrict__ keys, unsigned long long n,
+                                                                 unsigned long long vectors, uint32_t shift,
+                                                                 uint32_t bins, unsigned long long* __restrict__ counts)
 {
+    constexpr int THREADS = 1024, UNROLL = 4;
+    constexpr int VEC = 16 / sizeof(KeyT);
+    using VecT = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
     extern __shared__ uint32_t s_bins[];
-    for (uint32_t j = threadIdx.x; j < bins; j += 256) s_bins[j] = 0;
+    for (uint32_t j = threadIdx.x; j < bins; j += THREADS) s_bins[j] = 0;
     __syncthreads();
-    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256;
-    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride)
-        atomicAdd(&s_bins[static_cast<uint32_t>(keys[i] >> shift) & (bins - 1)], 1u);
+    const uint32_t mask = bins - 1;
+    auto count = [&](KeyT k) { atomicAdd(&s_bins[static_cast<uint32_t>(k >> shift) & mask], 1u); };
+    auto count_vec = [&](const VecT& x) {
+        count(x.x);
+        count(x.y);
+        if constexpr (sizeof(KeyT) == 4) {
+            count(x.z);
+            count(x.w);
+        }
+    };
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * THREADS;
+    const unsigned long long first = static_cast<unsigned long long>(blockIdx.x) * THREADS + threadIdx.x;
+    const VecT* __restrict__ vkeys = reinterpret_cast<const VecT*>(keys);
+    unsigned long long v = first;
+    for (; v + (UNROLL - 1) * stride < vectors; v += UNROLL * stride) {
+        VecT x[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) x[u] = vkeys[v + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) count_vec(x[u]);
+    }
+    for (; v < vectors; v += stride) count_vec(vkeys[v]);
+    // what the vectors do not cover: everything if the array is misaligned, else at most VEC - 1 keys
+    for (unsigned long long i = vectors * VEC + first; i < n; i += stride) count(keys[i]);
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < bins; j += 256) {
+    for (uint32_t j = threadIdx.x; j < bins; j += THREADS) {
         const uint32_t c = s_bins[j];
         if (c) atomicAdd(&counts[j], static_cast<unsigned long long>(c));
     }
@@ -726,18 +753,21 @@ extern "C" int mrs_bucket_histogram(mrs_context* ctx, const void* keys_dev, uint
     MRS_HIP_TRY(hipMemsetAsync(counts_dev, 0, bins * sizeof(uint64_t), s));
     if (n == 0) return MRS_OK;
     if (!keys_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_bucket_histogram: null keys");
-    uint64_t blocks = (n + 255) / 256;
-    const uint64_t cap = static_cast<uint64_t>(ctx->num_cus) * 8;
+    const uint64_t vec = key_words == 1 ? 4 : 2;
+    const uint64_t vectors = misaligned(keys_dev, 16) ? 0 : n / vec;
+    uint64_t blocks = ((vectors ? vectors : n) + 1024 * 4 - 1) / (1024 * 4);
+    const uint64_t cap = static_cast<uint64_t>(ctx->num_cus) * 2;
     if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
     unsigned long long* counts = reinterpret_cast<unsigned long long*>(counts_dev);
     if (key_words == 1)
-        hipLaunchKernelGGL(bucket_histogram_kernel<uint32_t>, dim3(blocks), dim3(256), bins * 4, s,
-                           static_cast<const uint32_t*>(keys_dev), static_cast<unsigned long long>(n), shift, bins,
-                           counts);
+        hipLaunchKernelGGL(bucket_histogram_kernel<uint32_t>, dim3(blocks), dim3(1024), bins * 4, s,
+                           static_cast<const uint32_t*>(keys_dev), static_cast<unsigned long long>(n),
+                           static_cast<unsigned long long>(vectors), shift, bins, counts);
     else
-        hipLaunchKernelGGL(bucket_histogram_kernel<unsigned long long>, dim3(blocks), dim3(256), bins * 4, s,
-                           static_cast<const unsigned long long*>(keys_dev), static_cast<unsigned long long>(n), shift,
-                           bins, counts);
+        hipLaunchKernelGGL(bucket_histogram_kernel<unsigned long long>, dim3(blocks), dim3(1024), bins * 4, s,
+                           static_cast<const unsigned long long*>(keys_dev), static_cast<unsigned long long>(n),
+                           static_cast<unsigned long long>(vectors), shift, bins, counts);
     MRS_CHECK_LAUNCH("bucket_histogram_kernel");
     return MRS_OK;
 }
