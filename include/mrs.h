@@ -218,7 +218,7 @@ int mrs_bucket_histogram(mrs_context* ctx, const void* keys_dev, uint64_t n,
                          uint64_t* counts_dev, void* stream);
 /* Stable partition of (key, payload) pairs into `num_parts` <= 16 contiguous
  * groups: an element goes to group map_dev[(key >> shift) & ((1<<bits)-1)]
- * (u8 table, 1 << bits entries).  Uses the plan's onesweep machinery (the plan
+ * (u8 table, 1 << bits entries, bits <= 12).  Uses the plan's onesweep machinery (the plan
  * must be MRS_ALGO_ONESWEEP).  part_counts_dev (u32[16], may be NULL) receives
  * the group sizes. */
 int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, const void* vals_in,

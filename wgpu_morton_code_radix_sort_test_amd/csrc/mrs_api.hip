@@ -782,8 +782,8 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_partition: the plan must be MRS_ALGO_ONESWEEP");
     if (num_parts == 0 || num_parts > 16 || num_parts > plan->radix)
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_partition: num_parts must be in [1, 16]");
-    if (bits == 0 || bits > 16 || shift + bits > 32u * plan->desc.key_words)
-        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_partition: need 1 <= bits <= 16 inside the key");
+    if (bits == 0 || (1u << bits) > static_cast<uint32_t>(kMaxMapEntries) || shift + bits > 32u * plan->desc.key_words)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_partition: need 1 <= bits <= 12 inside the key");
     if (!map_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_partition: null map");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) {

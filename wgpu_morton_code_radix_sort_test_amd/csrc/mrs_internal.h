@@ -37,6 +37,7 @@ void clear_error();
 constexpr int kMaxPasses = 16;   // 64-bit keys with 4-bit digits
 constexpr int kMaxRadix = 256;
 constexpr int kTicketLists = 8;  // one per accelerator die (XCD) of the MI355X
+constexpr int kMaxMapEntries = 4096;  // entries of a partition's digit table (12 key bits)
 
 // Per-launch arguments of a digit pass.
 struct PassArgs {

@@ -174,7 +174,12 @@ __global__ __launch_bounds__(1024) void global_histogram_banked_kernel(const Glo
     constexpr int VEC = 16 / sizeof(KeyT);
     constexpr int UNROLL = 4;  // vectors in flight per thread
     __shared__ uint32_t s_hist[B::COUNTERS * R];
+    __shared__ uint8_t s_map[ALL ? 1 : kMaxMapEntries];  // partition mode: the digit table
     for (int j = threadIdx.x; j < B::COUNTERS * R; j += THREADS) s_hist[j] = 0;
+    if constexpr (!ALL) {
+        if (a.digit_map)
+            for (uint32_t j = threadIdx.x; j <= a.map_mask && j < kMaxMapEntries; j += THREADS) s_map[j] = a.digit_map[j];
+    }
     __syncthreads();
 
     const KeyT* __restrict__ keys = static_cast<const KeyT*>(a.keys);
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(1024) void global_histogram_banked_kernel(const Glo
             // partition mode: one pass over at most 16 mapped digits, where the copies matter
             // most (a wave's 64 lanes would otherwise queue on a handful of words)
             if (a.digit_map) {
-                const uint32_t d = a.digit_map[static_cast<uint32_t>(k >> a.begin_bit) & a.map_mask];
+                const uint32_t d = s_map[static_cast<uint32_t>(k >> a.begin_bit) & a.map_mask];
                 atomicAdd(&s_hist[d * R + copy], 1u);
                 return;
             }

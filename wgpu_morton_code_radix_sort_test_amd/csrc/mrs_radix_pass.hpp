@@ -639,6 +639,14 @@ __global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) voi
         b.keys_out = other_side ? const_cast<void*>(a.keys_in) : a.keys_out;
         b.vals_out = other_side ? const_cast<void*>(a.vals_in) : a.vals_out;
         run_digit_pass<MODE, RANK, MAP, StatusT>(b, sh);
+    } else if constexpr (MAP) {
+        // The digit table (at most kMaxMapEntries bytes) is read three times per key: keep it in
+        // LDS.  The first barrier of run_digit_pass orders these stores before any lookup.
+        __shared__ uint8_t s_map[kMaxMapEntries];
+        for (uint32_t j = threadIdx.x; j <= a.mask && j < kMaxMapEntries; j += THREADS) s_map[j] = a.digit_map[j];
+        PassArgs b = a;
+        b.digit_map = s_map;
+        run_digit_pass<MODE, RANK, MAP, StatusT>(b, sh);
     } else {
         run_digit_pass<MODE, RANK, MAP, StatusT>(a, sh);
     }
