@@ -648,6 +648,11 @@ def test_errors_are_reported(ctx, mrs):
         plan.sort_pairs(k, k, k, k, n=1000)  # A and B must differ
     with pytest.raises(mrs.MrsError):
         plan.sort_pairs(k, k, k.clone(), k.clone(), n=2000)  # beyond capacity
+    table = torch.zeros(1 << 13, dtype=torch.uint8, device=ctx.device)
+    with pytest.raises(mrs.MrsError):
+        plan.partition(k, k.clone(), k.clone(), k.clone(), 0, 13, table, 2, n=1000)  # tables hold at most 2^12 entries
+    with pytest.raises(mrs.MrsError):
+        plan.partition(k, k.clone(), k.clone(), k.clone(), 0, 12, table, 17, n=1000)  # at most 16 parts
 
 
 @pytest.mark.parametrize("extra", [[], ["--gather"], ["--algo", "three_kernel"], ["--triangles", "70001", "--vertices", "5000", "--gather"],
