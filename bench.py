@@ -271,7 +271,10 @@ def main():
                     plan.morton_encode30_for_sort(xyz, mn, mx, ek, ei)
                 else:
                     ctx.morton_encode30(xyz, mn, mx, ek, ei)
-                plan.sort_pairs(ek, ei, kb, vb)
+                if primed:
+                    plan.sort_pairs_primed(ek, ei, kb, vb)
+                else:
+                    plan.sort_pairs(ek, ei, kb, vb)
                 p1.record()
                 torch.cuda.synchronize()
                 times.append(p0.elapsed_time(p1))

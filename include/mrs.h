@@ -107,10 +107,14 @@ int mrs_context_destroy(mrs_context* ctx);
                                     consecutive tiles to workgroups of one die               */
 int mrs_context_get_attribute(const mrs_context* ctx, int attribute, int64_t* value);
 /* MRS_ATTR_DIE_AWARE_TICKETS can be cleared (value 0) and, where the creation-time check passed,
- * set again.  Clear it when several sorts run concurrently on one device: with die-aware tickets
- * a pass makes progress only if it keeps getting workgroup slots on every die, which a second
- * long-running kernel can deny it (the pass then ends in MRS_ERR_DEVICE_TIMEOUT after 4 s instead
- * of completing).  Sorts that follow each other on one stream, the normal case, are not affected. */
+ * set again.  With die-aware tickets a pass makes progress only if it keeps getting workgroup
+ * slots on every die.  The library itself never runs two such passes at once on a device: a sort
+ * call that finds the previous die-aware call of the process on that device still running on
+ * ANOTHER stream uses a single ticket list for its own passes (which needs one free slot
+ * anywhere), so sorts on several streams or contexts can overlap freely.  What the library cannot
+ * see is a foreign kernel that occupies every compute unit of a die for seconds, or sorts replayed
+ * concurrently from captured graphs: clear the attribute for such uses (a starved pass ends in
+ * MRS_ERR_DEVICE_TIMEOUT after 4 s instead of completing). */
 int mrs_context_set_attribute(mrs_context* ctx, int attribute, int64_t value);
 
 /* ---- plan: replaces create_all_buffers' temporaries (histogram + prefix_sums,
@@ -119,8 +123,11 @@ int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* desc, mrs_plan** out)
 int mrs_plan_destroy(mrs_plan* plan);
 int mrs_plan_get_info(const mrs_plan* plan, mrs_plan_info* info);
 /* Synchronises `stream` and reports MRS_ERR_DEVICE_TIMEOUT if a chained-scan
- * kernel gave up waiting for a predecessor tile since the last check.  For
- * tests and harnesses; not needed on the hot path. */
+ * kernel gave up waiting for a predecessor tile since the last check (the
+ * output of that call is invalid, and later passes of the plan give up early
+ * until the flag has been read).  The sort calls only enqueue work and cannot
+ * report it themselves: a production caller checks once per batch, at a point
+ * where it synchronises anyway. */
 int mrs_plan_check(mrs_plan* plan, void* stream);
 /* Synchronises `stream` and reports, for the most recent mrs_sort_pairs call on
  * an MRS_ALGO_ONESWEEP plan, which passes the device left out: bit p of
@@ -167,7 +174,9 @@ int mrs_morton_encode30(mrs_context* ctx, const float* xyz_dev, uint64_t n,
  * (on the host, immediately) to 1 when the sorted data ends in the B buffers,
  * i.e. when the number of passes is odd (src/main.rs:819-823).  n <= plan n.
  * vals_* may be NULL when payload_bytes == 0.  The pair of buffers that does
- * not hold the result is scratch.  MRS_ALGO_ONESWEEP plans for 64-bit keys
+ * not hold the result is scratch.  Buffers need the alignment of their element
+ * (4 or 8 bytes for keys, payload_bytes for the payload), nothing more: the
+ * kernels' 16-byte loads run in gfx950's unaligned access mode.  MRS_ALGO_ONESWEEP plans for 64-bit keys
  * leave out, on the device, passes whose digit is the same for every key (the
  * constant high bytes of a short code); they are left out in pairs, so the
  * result side stays the one reported here. */
@@ -189,13 +198,18 @@ int mrs_scatter(mrs_plan* plan, uint64_t n, const void* keys_in, const void* val
                 uint32_t pass, void* stream);
 
 /* mrs_morton_encode30 that also leaves the digit histograms of the keys it writes in `plan` (an
- * MRS_ALGO_ONESWEEP plan for 32-bit keys), so that the next mrs_sort_pairs(plan, n, keys_dev, ...)
- * with the same keys pointer and n skips its own read of the keys (the histogram launch before the
- * passes, src/main.rs:594-603 being the reference's per-pass counterpart).  The keys must reach
- * that call unchanged; any other mrs_sort_pairs call on the plan drops the histograms.  The plan's
- * memory is used, so the call must be ordered before the sort on one stream. */
+ * MRS_ALGO_ONESWEEP plan for 32-bit keys), so that mrs_sort_pairs_primed(plan, n, keys_dev, ...)
+ * can skip its own read of the keys (the histogram launch before the passes, src/main.rs:594-603
+ * being the reference's per-pass counterpart).  The plan's memory is used, so the call must be
+ * ordered before the sort on one stream.  Any other call that takes the plan drops the histograms. */
 int mrs_morton_encode30_for_sort(mrs_plan* plan, const float* xyz_dev, uint64_t n, const float* mn,
                                  const float* mx, uint32_t* keys_dev, uint32_t* idx_dev, void* stream);
+/* mrs_sort_pairs that consumes the histograms mrs_morton_encode30_for_sort left in the plan.
+ * Fails with MRS_ERR_INVALID_ARGUMENT unless it is the first call on the plan after that encoder
+ * call and keys_a and n are the encoder's keys_dev and n; the caller vouches that the keys have
+ * not been written since.  mrs_sort_pairs itself never uses left-over histograms. */
+int mrs_sort_pairs_primed(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b,
+                          void* vals_b, void* stream, int* result_in_b);
 
 /* Sort by key, moving each wide record once: the variant the reference's own comments
  * anticipate for TriangleIndices (src/types.rs:26-36, src/shaders/radix_sort_index.wgsl:3-6)

@@ -329,20 +329,88 @@ def test_encode_for_sort_primes_the_plan(ctx, oracle, mrs, bits, begin, end):
     keys, idx = plan.morton_encode30_for_sort(to_dev(xyz, ctx.device), mn, mx)
     assert np.array_equal(to_u32(keys), rk) and np.array_equal(to_u32(idx), ri)
     kb, vb = torch.empty_like(keys), torch.empty_like(idx)
-    in_b = plan.sort_pairs(keys, idx, kb, vb)
+    in_b = plan.sort_pairs_primed(keys, idx, kb, vb)
     plan.check()
     assert "global_histogram" not in [lab for lab, _ in plan.timings()]
     sk, sv = oracle.stable_sort_pairs(rk, ri, n, 1, 1, begin, end)
     assert np.array_equal(to_u32(kb if in_b else keys), sk) and np.array_equal(to_u32(vb if in_b else idx), sv)
-    # the histograms are used once: the next sort computes its own
+    # the histograms are used once: a second primed call is refused, a plain sort computes its own
     other = make_keys(oracle, n, 1, "random")
     ok, ov = to_dev(other, ctx.device), to_dev(ri, ctx.device)
+    with pytest.raises(mrs.MrsError):
+        plan.sort_pairs_primed(ok, ov, kb, vb)
     in_b = plan.sort_pairs(ok, ov, kb, vb)
     plan.check()
     assert "global_histogram" in [lab for lab, _ in plan.timings()]
     sk, sv = oracle.stable_sort_pairs(other, ri, n, 1, 1, begin, end)
     assert np.array_equal(to_u32(kb if in_b else ok), sk) and np.array_equal(to_u32(vb if in_b else ov), sv)
     plan.close()
+
+
+def test_left_over_histograms_are_never_used_by_accident(ctx, oracle, mrs):
+    """Sequences that once made a sort run on stale digit histograms: the encoder, then (a) other
+    keys written to the same address and a plain sort, (b) a partition on the plan and a sort of
+    the encoder's keys.  Both sorts must compute their own histograms; a primed sort after the
+    partition is refused."""
+    n = 150001
+    xyz = oracle.gen_points(11, n)
+    mn, mx = oracle.minmax3(xyz)
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8)
+    kb, vb = (torch.empty(n, dtype=torch.int32, device=ctx.device) for _ in range(2))
+    # (a) same pointer, same n, different contents
+    keys, idx = plan.morton_encode30_for_sort(to_dev(xyz, ctx.device), mn, mx)
+    other = make_keys(oracle, n, 1, "random", seed=99)
+    keys.copy_(to_dev(other, ctx.device))
+    hv = to_u32(idx)
+    in_b = plan.sort_pairs(keys, idx, kb, vb)
+    plan.check()
+    sk, sv = oracle.stable_sort_pairs(other, hv, n, 1, 1, 0, 32)
+    assert np.array_equal(to_u32(kb if in_b else keys), sk) and np.array_equal(to_u32(vb if in_b else idx), sv)
+    # (b) encoder, partition on the same plan, then sorts of the encoder's keys
+    keys, idx = plan.morton_encode30_for_sort(to_dev(xyz, ctx.device), mn, mx, keys, idx)
+    hk, hv = to_u32(keys), to_u32(idx)
+    table = torch.zeros(256, dtype=torch.uint8, device=ctx.device)
+    table[128:] = 1
+    plan.partition(keys, idx, kb, vb, 22, 8, table, 2)
+    with pytest.raises(mrs.MrsError):
+        plan.sort_pairs_primed(keys, idx, kb, vb)
+    in_b = plan.sort_pairs(keys, idx, kb, vb)
+    plan.check()
+    sk, sv = oracle.stable_sort_pairs(hk, hv, n, 1, 1, 0, 32)
+    assert np.array_equal(to_u32(kb if in_b else keys), sk) and np.array_equal(to_u32(vb if in_b else idx), sv)
+    plan.close()
+
+
+def test_sort_from_misaligned_slices(ctx, oracle, mrs):
+    """Key, payload and scratch buffers that start 4 bytes past a 16-byte boundary: the histogram
+    and index kernels use 16-byte vector accesses, which gfx950 serves at element alignment."""
+    n = 70001
+    keys = make_keys(oracle, n, 1, "random", seed=5)
+    vals = make_vals(oracle, n, 1)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+    big = [torch.zeros(n + 8, dtype=torch.int32, device=ctx.device) for _ in range(4)]
+    ka, va, kb, vb = (t[1:n + 1] for t in big)
+    assert ka.data_ptr() % 16 == 4
+    for algo in (mrs.ALGO_ONESWEEP, mrs.ALGO_THREE_KERNEL):
+        ka.copy_(to_dev(keys, ctx.device))
+        va.copy_(to_dev(vals, ctx.device))
+        plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, algo=algo)
+        in_b = plan.sort_pairs(ka, va, kb, vb)
+        plan.check()
+        assert np.array_equal(to_u32(kb if in_b else ka), rk) and np.array_equal(to_u32(vb if in_b else va), rv)
+        plan.close()
+    # mrs_sort_gather: the index buffers are filled with 16-byte stores
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8)
+    ka.copy_(to_dev(keys, ctx.device))
+    recs = to_dev(vals, ctx.device)
+    rout = torch.empty_like(recs)
+    in_b, index = plan.sort_gather(ka, kb, recs, rout, 4, index_a=va, index_b=vb)
+    plan.check()
+    assert np.array_equal(to_u32(kb if in_b else ka), rk) and np.array_equal(to_u32(rout), rv)
+    plan.close()
+    # the bounds of the slices were respected
+    for t in big:
+        assert int(t[0]) == 0 and int(t[n + 1:].abs().sum()) == 0
 
 
 def test_context_attributes(ctx):
@@ -373,12 +441,12 @@ def test_single_ticket_list(oracle, mrs):
 
 
 def test_concurrent_sorts_on_two_streams(oracle, mrs):
-    """Two plans sorting at the same time on two streams of one device, with the die-aware tile
-    assignment switched off as documented for this use: with a single ticket list the lowest
-    unfinished tile of either kernel is always held by a running workgroup, so the two kernels can
-    share the compute units in any interleaving."""
+    """Two plans sorting at the same time on two streams of one device, every attribute at its
+    default: a call that finds a die-aware sort of another stream still in flight runs with a
+    single ticket list (the lowest unfinished tile of such a kernel is always held by a running
+    workgroup), so the kernels can share the compute units in any interleaving."""
     ctx2 = mrs.Context(0)
-    ctx2.set_attribute(ctx2.ATTR_DIE_AWARE_TICKETS, 0)
+    assert ctx2.attribute(ctx2.ATTR_DIE_AWARE_TICKETS) == 1
     n = (1 << 21) + 4321
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     plans = [mrs.SortPlan(ctx2, n), mrs.SortPlan(ctx2, n)]

@@ -207,9 +207,21 @@ class SortPlan:
         )
         return bool(in_b.value)
 
+    def sort_pairs_primed(self, keys_a, vals_a, keys_b, vals_b, n=None, stream=None):
+        """`mrs_sort_pairs_primed`: sort_pairs that uses the histograms morton_encode30_for_sort left
+        in this plan for exactly these keys (raises MrsError if the plan does not hold them)."""
+        n = self.n if n is None else n
+        self._check_sizes(n, (keys_a, keys_b), (vals_a, vals_b))
+        in_b = ctypes.c_int(0)
+        _lib.check(
+            self.lib.mrs_sort_pairs_primed(self._h, n, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
+                                           _stream(stream), ctypes.byref(in_b))
+        )
+        return bool(in_b.value)
+
     def morton_encode30_for_sort(self, xyz, mn, mx, keys_out=None, idx_out=None, stream=None):
         """`mrs_morton_encode30_for_sort`: the encoder that also leaves the digit histograms of the
-        keys in this plan; pass the returned key tensor to sort_pairs as keys_a, unchanged."""
+        keys in this plan; pass the returned key tensor to sort_pairs_primed as keys_a, unchanged."""
         n = xyz.numel() // 3
         if xyz.dtype != torch.float32:
             raise ValueError("xyz must be float32")

@@ -6,6 +6,7 @@
 // (src/main.rs:515-576), with no host synchronisation in between.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "mrs_internal.h"
@@ -96,6 +97,33 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 constexpr size_t kControlBytes = (sizeof(OnesweepControl) + 255) / 256 * 256;
 
+// ---- which sorts may use die-aware tickets --------------------------------------------------
+// Two chained-scan passes that both deal their tiles per die can block each other when they run
+// at the same time (each may hold the compute units of a die the other needs a slot on), so at
+// most one such pass may be in flight per device.  Every sort call that uses die-aware tickets
+// leaves an event behind its last launch; a call on another stream that finds the event of the
+// previous call still pending runs with a single ticket list, whose progress needs nothing but
+// one free slot anywhere.  A single-list pass and a die-aware pass can share the device.
+constexpr int kMaxDevices = 64;
+struct DeviceActivity {
+    std::mutex m;
+    hipEvent_t event = nullptr;  // created by mrs_context_create with the device current
+    hipStream_t stream = nullptr;
+    bool recorded = false;
+};
+static DeviceActivity g_activity[kMaxDevices];
+
+static bool stream_is_capturing(hipStream_t s)
+{
+    if (!s) return false;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
 static int check_device(const mrs_context* ctx, const char* who)
 {
     int cur = -1;
@@ -123,6 +151,38 @@ static uint32_t xcd_block_tiles(const mrs_context* ctx)
     static const int env = std::getenv("MRS_XCD_BLOCK") ? std::atoi(std::getenv("MRS_XCD_BLOCK")) : -1;
     if (!ctx->die_aware_tickets) return 0;
     return env >= 0 ? static_cast<uint32_t>(env) : 8u;
+}
+
+// Ticket block size for the chained-scan passes of one call on stream `s`: the context's, unless
+// a die-aware call on another stream of this device may still be running (DeviceActivity).
+// Under stream capture nothing can be queried: the captured work keeps the context's setting,
+// and replays that overlap on one device are the caller's to avoid.
+static uint32_t begin_ticketed_call(const mrs_context* ctx, hipStream_t s)
+{
+    uint32_t block = xcd_block_tiles(ctx);
+    if (block == 0 || stream_is_capturing(s)) return block;
+    DeviceActivity& a = g_activity[ctx->device];
+    std::lock_guard<std::mutex> lock(a.m);
+    if (a.recorded && a.stream != s && a.event) {
+        if (hipEventQuery(a.event) != hipSuccess) block = 0;
+        (void)hipGetLastError();  // "not ready" is an answer, not an error to report later
+    }
+    return block;
+}
+
+// Leaves the mark the next call looks for.  Only calls that did use die-aware tickets need one.
+static void end_ticketed_call(const mrs_context* ctx, hipStream_t s, uint32_t block)
+{
+    if (block == 0 || stream_is_capturing(s)) return;
+    DeviceActivity& a = g_activity[ctx->device];
+    std::lock_guard<std::mutex> lock(a.m);
+    if (!a.event) return;
+    if (hipEventRecord(a.event, s) == hipSuccess) {
+        a.stream = s;
+        a.recorded = true;
+    } else {
+        (void)hipGetLastError();
+    }
 }
 
 static int launch_pass(const mrs_plan* p, int mode, const PassArgs& args, hipStream_t s)
@@ -284,7 +344,10 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
         return fail(MRS_ERR_UNSUPPORTED, "mrs_context_create: device %d is %s; this library is built for gfx950 only",
                     device_id, prop.gcnArchName);
     // Which ranking the digit passes use on this device (MRS_RANK=match skips the faster one).
+    if (device_id >= kMaxDevices)
+        return fail(MRS_ERR_UNSUPPORTED, "mrs_context_create: at most %d devices are supported", kMaxDevices);
     bool in_order = false, all_dies = false;
+    void* scratch_ptr = nullptr;
     const char* rank_env = std::getenv("MRS_RANK");
     {
         int prev = -1;
@@ -293,6 +356,17 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
         int rc = MRS_OK;
         if (!(rank_env && std::strcmp(rank_env, "match") == 0)) rc = probe_lds_atomic_order(&in_order);
         if (rc == MRS_OK && prop.multiProcessorCount == 256) rc = probe_die_ids(&all_dies);
+        if (rc == MRS_OK) {
+            DeviceActivity& a = g_activity[device_id];
+            std::lock_guard<std::mutex> lock(a.m);
+            if (!a.event) {
+                hipError_t e = hipEventCreateWithFlags(&a.event, hipEventDisableTiming);
+                if (e != hipSuccess) {
+                    a.event = nullptr;
+                    rc = fail(MRS_ERR_HIP, "mrs_context_create: hipEventCreate failed: %s", hipGetErrorString(e));
+                }
+            }
+        }
         MRS_HIP_TRY(hipSetDevice(prev));
         if (rc) return rc;
     }
@@ -302,6 +376,8 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
     c->lds_atomics_in_lane_order = in_order;
     c->workgroups_on_all_dies = all_dies;
     c->die_aware_tickets = all_dies;
+    c->live_plans = 0;
+    c->static_scratch = scratch_ptr;
     *out = c;
     return MRS_OK;
 }
@@ -333,31 +409,28 @@ extern "C" int mrs_context_set_attribute(mrs_context* ctx, int attribute, int64_
 extern "C" int mrs_context_destroy(mrs_context* ctx)
 {
     clear_error();
+    if (ctx && ctx->live_plans != 0)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_destroy: %d plan(s) of this context are still alive; destroy them first",
+                    ctx->live_plans);
     delete ctx;
     return MRS_OK;
 }
 
-extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_plan** out)
+// Validates a plan description and fills every field of `p` that does not depend on memory:
+// shape, pass count, tile count.  `p` must be zero-initialised.
+static int fill_plan(mrs_plan* p, mrs_context* ctx, const mrs_plan_desc* d, const char* who)
 {
-    clear_error();
-    if (!ctx || !d || !out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_create: null argument");
-    *out = nullptr;
-    if (int rc = check_device(ctx, "mrs_plan_create")) return rc;
-    if (d->n == 0 || d->n >= 0xFFFFFFFFull)
-        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_create: n must satisfy 0 < n < 2^32 - 1");
+    if (d->n == 0 || d->n >= 0xFFFFFFFFull) return fail(MRS_ERR_INVALID_ARGUMENT, "%s: n must satisfy 0 < n < 2^32 - 1", who);
     if (d->algo != MRS_ALGO_THREE_KERNEL && d->algo != MRS_ALGO_ONESWEEP)
-        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_create: unknown algo %d", d->algo);
+        return fail(MRS_ERR_INVALID_ARGUMENT, "%s: unknown algo %d", who, d->algo);
     KernelConfig cfg;
     if (!config_supported(d->n, d->key_words, d->payload_bytes, d->digit_bits, d->tile_items, d->algo, &cfg))
-        return fail(MRS_ERR_UNSUPPORTED,
-                    "mrs_plan_create: unsupported shape (key_words %d, payload_bytes %d, digit_bits %d, tile_items %d)",
-                    d->key_words, d->payload_bytes, d->digit_bits, d->tile_items);
+        return fail(MRS_ERR_UNSUPPORTED, "%s: unsupported shape (key_words %d, payload_bytes %d, digit_bits %d, tile_items %d)",
+                    who, d->key_words, d->payload_bytes, d->digit_bits, d->tile_items);
     const int key_bits = 32 * d->key_words;
     if (d->begin_bit < 0 || d->end_bit > key_bits || d->begin_bit >= d->end_bit)
-        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_create: bit range [%d, %d) invalid for a %d-bit key",
-                    d->begin_bit, d->end_bit, key_bits);
-
-    mrs_plan* p = new mrs_plan();
+        return fail(MRS_ERR_INVALID_ARGUMENT, "%s: bit range [%d, %d) invalid for a %d-bit key", who, d->begin_bit,
+                    d->end_bit, key_bits);
     p->ctx = ctx;
     p->desc = *d;
     p->radix_bits = d->digit_bits;
@@ -369,11 +442,48 @@ extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_pla
     p->desc.tile_items = p->tile_items;
     p->max_tiles = (d->n + p->tile_items - 1) / p->tile_items;
     p->histogram_len = static_cast<uint64_t>(p->radix) * p->max_tiles;
-    if (p->num_passes > static_cast<uint32_t>(kMaxPasses)) {
-        delete p;
-        return fail(MRS_ERR_UNSUPPORTED, "mrs_plan_create: too many passes");
+    if (p->num_passes > static_cast<uint32_t>(kMaxPasses)) return fail(MRS_ERR_UNSUPPORTED, "%s: too many passes", who);
+    if (d->algo == MRS_ALGO_ONESWEEP) {
+        // 32-bit status words carry counts below 2^30; the kernels instantiated for them also
+        // address keys and payload with 32-bit byte offsets, so no array may exceed 4 GiB
+        const unsigned long long elem_bytes =
+            std::max<unsigned long long>(4ull * d->key_words, static_cast<unsigned long long>(d->payload_bytes));
+        p->status_word_bytes = (d->n < (1ull << 30) && d->n * elem_bytes <= (1ull << 32)) ? 4 : 8;
+        // test aid: the 64-bit instantiation on inputs small enough to check element by element
+        if (std::getenv("MRS_FORCE_WIDE_STATUS")) p->status_word_bytes = 8;
     }
+    return MRS_OK;
+}
 
+// Device bytes a onesweep plan needs: [error flag, 256 B][control block][status words].
+static size_t onesweep_temp_bytes(const mrs_plan* p)
+{
+    return 256 + kControlBytes +
+           align_up(p->histogram_len * p->status_word_bytes * static_cast<size_t>(p->num_passes), 256);
+}
+
+// Points the plan at `temp`, a zeroed block of onesweep_temp_bytes(p) bytes.  Everything after
+// the error flag is cleared by one memset at the start of every sort call.
+static void bind_onesweep_memory(mrs_plan* p, void* temp)
+{
+    p->temp = temp;
+    p->error_flag = static_cast<uint32_t*>(temp);
+    p->zero_begin = static_cast<char*>(temp) + 256;
+    p->control = reinterpret_cast<OnesweepControl*>(p->zero_begin);
+    p->status = p->zero_begin + kControlBytes;
+}
+
+extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_plan** out)
+{
+    clear_error();
+    if (!ctx || !d || !out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_create: null argument");
+    *out = nullptr;
+    if (int rc = check_device(ctx, "mrs_plan_create")) return rc;
+    mrs_plan* p = new mrs_plan();
+    if (int rc = fill_plan(p, ctx, d, "mrs_plan_create")) {
+        delete p;
+        return rc;
+    }
     size_t bytes = 0;
     if (d->algo == MRS_ALGO_THREE_KERNEL) {
         const size_t hist_bytes = align_up(p->histogram_len * sizeof(uint32_t), 256);
@@ -388,27 +498,14 @@ extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_pla
         p->hist = static_cast<uint32_t*>(p->temp);
         p->scan_partials = reinterpret_cast<uint32_t*>(static_cast<char*>(p->temp) + hist_bytes);
     } else {
-        // 32-bit status words carry counts below 2^30; the kernels instantiated for them also
-        // address keys and payload with 32-bit byte offsets, so no array may exceed 4 GiB
-        const unsigned long long elem_bytes =
-            std::max<unsigned long long>(4ull * d->key_words, static_cast<unsigned long long>(d->payload_bytes));
-        p->status_word_bytes = (d->n < (1ull << 30) && d->n * elem_bytes <= (1ull << 32)) ? 4 : 8;
-        // test aid: the 64-bit instantiation on inputs small enough to check element by element
-        if (std::getenv("MRS_FORCE_WIDE_STATUS")) p->status_word_bytes = 8;
-        const size_t status_bytes =
-            align_up(p->histogram_len * p->status_word_bytes * static_cast<size_t>(p->num_passes), 256);
-        bytes = 256 + kControlBytes + status_bytes;
-        hipError_t e = hipMalloc(&p->temp, bytes);
+        bytes = onesweep_temp_bytes(p);
+        void* temp = nullptr;
+        hipError_t e = hipMalloc(&temp, bytes);
         if (e != hipSuccess) {
             delete p;
             return fail(MRS_ERR_OUT_OF_MEMORY, "mrs_plan_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         }
-        // [error flag, 256 B][control block][status words]; everything after the flag is
-        // cleared by one memset at the start of every sort call
-        p->error_flag = static_cast<uint32_t*>(p->temp);
-        p->zero_begin = static_cast<char*>(p->temp) + 256;
-        p->control = reinterpret_cast<OnesweepControl*>(p->zero_begin);
-        p->status = p->zero_begin + kControlBytes;
+        bind_onesweep_memory(p, temp);
         e = hipMemset(p->temp, 0, bytes);
         if (e != hipSuccess) {
             (void)hipFree(p->temp);
@@ -417,6 +514,8 @@ extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_pla
         }
     }
     p->temp_bytes = bytes;
+    p->owns_temp = true;
+    ctx->live_plans++;
     *out = p;
     return MRS_OK;
 }
@@ -429,7 +528,8 @@ extern "C" int mrs_plan_destroy(mrs_plan* plan)
         const int cap = static_cast<int>(sizeof(plan->marks) / sizeof(plan->marks[0]));
         for (int i = 0; i < cap; ++i) (void)hipEventDestroy(plan->marks[i]);
     }
-    if (plan->temp) (void)hipFree(plan->temp);
+    if (plan->temp && plan->owns_temp) (void)hipFree(plan->temp);
+    if (plan->ctx) plan->ctx->live_plans--;
     delete plan;
     return MRS_OK;
 }
@@ -497,22 +597,19 @@ static int check_pair_buffers(const mrs_plan* plan, const void* ka, const void* 
     return MRS_OK;
 }
 
-extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b,
-                              void* stream, int* result_in_b)
+// The launch schedule shared by mrs_sort_pairs and mrs_sort_pairs_primed.
+// `primed`: the plan's control block already holds the digit histograms of exactly these keys.
+static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b,
+                           hipStream_t s, int* result_in_b, bool primed, const char* who)
 {
-    clear_error();
-    if (int rc = validate_call(plan, n, "mrs_sort_pairs")) return rc;
     // result side by pass parity, src/main.rs:819-823
     if (result_in_b) *result_in_b = (plan->num_passes % 2u) == 1u;
+    plan->primed_keys = nullptr;  // whatever happens below, the histograms of an encoder call are spent
     if (n == 0) return MRS_OK;
-    if (int rc = check_pair_buffers(plan, keys_a, vals_a, keys_b, vals_b, "mrs_sort_pairs")) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = check_pair_buffers(plan, keys_a, vals_a, keys_b, vals_b, who)) return rc;
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
 
-    // histograms left by mrs_morton_encode30_for_sort for exactly these keys?
-    const bool primed = plan->primed_keys == keys_a && plan->primed_n == n && plan->desc.algo == MRS_ALGO_ONESWEEP;
-    plan->primed_keys = nullptr;
     plan->pass_plan_live = false;
     plan->num_marks = 0;
     if (int rc = mark(plan, "start", s)) return rc;
@@ -538,7 +635,9 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
     static const bool no_pass_skip = std::getenv("MRS_NO_PASS_SKIP") != nullptr;
     const bool skip_passes = plan->desc.algo == MRS_ALGO_ONESWEEP && plan->desc.key_words == 2 && !no_pass_skip;
     plan->pass_plan_live = skip_passes;
+    uint32_t xcd_block = 0;
     if (plan->desc.algo == MRS_ALGO_ONESWEEP) {
+        xcd_block = begin_ticketed_call(plan->ctx, s);
         const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
         const size_t zero = kControlBytes + align_up(region * plan->num_passes, 256);
         // a primed plan keeps its histograms: only the ticket counters and the status words are cleared
@@ -590,7 +689,7 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
             a.status = plan->status + static_cast<size_t>(pass) * num_tiles * plan->radix * plan->status_word_bytes;
             a.wide_status = plan->status_word_bytes == 8;
             a.tile_counter = plan->control->tile_counter[pass];
-            a.xcd_block = xcd_block_tiles(plan->ctx);
+            a.xcd_block = xcd_block;
             a.error_flag = plan->error_flag;
             a.pass_plan = skip_passes ? plan->control->pass_plan + pass : nullptr;
 #ifdef MRS_STAMPS
@@ -601,7 +700,33 @@ extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* va
             if (int rc = mark(plan, "onesweep_pass", s)) return rc;
         }
     }
+    if (plan->desc.algo == MRS_ALGO_ONESWEEP) end_ticketed_call(plan->ctx, s, xcd_block);
     return MRS_OK;
+}
+
+extern "C" int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b,
+                              void* stream, int* result_in_b)
+{
+    clear_error();
+    if (int rc = validate_call(plan, n, "mrs_sort_pairs")) return rc;
+    return sort_pairs_impl(plan, n, keys_a, vals_a, keys_b, vals_b, static_cast<hipStream_t>(stream), result_in_b, false,
+                           "mrs_sort_pairs");
+}
+
+extern "C" int mrs_sort_pairs_primed(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b,
+                                     void* stream, int* result_in_b)
+{
+    clear_error();
+    if (int rc = validate_call(plan, n, "mrs_sort_pairs_primed")) return rc;
+    if (plan->primed_keys == nullptr || plan->primed_keys != keys_a || plan->primed_n != n) {
+        plan->primed_keys = nullptr;
+        return fail(MRS_ERR_INVALID_ARGUMENT,
+                    "mrs_sort_pairs_primed: the plan does not hold the histograms of these keys: the call must follow "
+                    "mrs_morton_encode30_for_sort on the same plan, with its keys_dev and n, and no other call on the "
+                    "plan in between");
+    }
+    return sort_pairs_impl(plan, n, keys_a, vals_a, keys_b, vals_b, static_cast<hipStream_t>(stream), result_in_b, true,
+                           "mrs_sort_pairs_primed");
 }
 
 extern "C" int mrs_plan_set_timing(mrs_plan* plan, int enable)
@@ -791,6 +916,10 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
         return MRS_OK;
     }
     if (int rc = check_pair_buffers(plan, keys_in, vals_in, keys_out, vals_out, "mrs_partition")) return rc;
+    // the control block is about to be overwritten: histograms an encoder left are gone, and
+    // the record of which passes the last sort left out no longer describes it
+    plan->primed_keys = nullptr;
+    plan->pass_plan_live = false;
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
     const size_t zero =
@@ -826,7 +955,9 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
     a.status = plan->status;
     a.wide_status = plan->status_word_bytes == 8;
     a.tile_counter = plan->control->tile_counter[0];
-    a.xcd_block = xcd_block_tiles(plan->ctx);
+    a.xcd_block = begin_ticketed_call(plan->ctx, s);
     a.error_flag = plan->error_flag;
-    return launch_pass(plan, kModeOnesweep, a, s);
+    if (int rc = launch_pass(plan, kModeOnesweep, a, s)) return rc;
+    end_ticketed_call(plan->ctx, s, a.xcd_block);
+    return MRS_OK;
 }

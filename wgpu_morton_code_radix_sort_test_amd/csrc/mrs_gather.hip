@@ -7,14 +7,18 @@ namespace mrs {
 
 namespace {
 
+// 64-bit loop indices: n may lie within one grid stride of 2^32, where a 32-bit index would wrap
+// to a value below n and never leave the loop.
 __global__ __launch_bounds__(256) void iota_kernel(uint32_t* __restrict__ out, uint32_t n)
 {
-    const uint32_t stride = gridDim.x * 256u * 4u;
-    for (uint32_t base = (blockIdx.x * 256u + threadIdx.x) * 4u; base < n; base += stride) {
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256u * 4u;
+    for (unsigned long long base = (static_cast<unsigned long long>(blockIdx.x) * 256u + threadIdx.x) * 4u; base < n;
+         base += stride) {
+        const uint32_t b = static_cast<uint32_t>(base);
         if (base + 3 < n) {
-            *reinterpret_cast<uint4*>(out + base) = make_uint4(base, base + 1, base + 2, base + 3);
+            *reinterpret_cast<uint4*>(out + base) = make_uint4(b, b + 1, b + 2, b + 3);
         } else {
-            for (uint32_t i = base; i < n; ++i) out[i] = i;
+            for (unsigned long long i = base; i < n; ++i) out[i] = static_cast<uint32_t>(i);
         }
     }
 }
@@ -24,8 +28,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void gather_kernel(const T* __restrict__ in, const uint32_t* __restrict__ index,
                                                      T* __restrict__ out, uint32_t n)
 {
-    const uint32_t stride = gridDim.x * 256u;
-    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += stride) out[j] = in[index[j]];
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256u;
+    for (unsigned long long j = static_cast<unsigned long long>(blockIdx.x) * 256u + threadIdx.x; j < n; j += stride)
+        out[j] = in[index[j]];
 }
 
 // records of `words` 32-bit words, any count: one thread per word

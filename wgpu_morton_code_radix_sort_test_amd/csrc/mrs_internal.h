@@ -38,6 +38,8 @@ constexpr int kMaxPasses = 16;   // 64-bit keys with 4-bit digits
 constexpr int kMaxRadix = 256;
 constexpr int kTicketLists = 8;  // one per accelerator die (XCD) of the MI355X
 constexpr int kMaxMapEntries = 4096;  // entries of a partition's digit table (12 key bits)
+constexpr int kMaxSplitters = 15;     // key values a partition can split at (16 destinations)
+constexpr uint32_t kMapBySplitters = 0xFFu;  // digit table entry: this bucket holds a splitter
 
 // Per-launch arguments of a digit pass.
 struct PassArgs {
@@ -50,6 +52,12 @@ struct PassArgs {
     uint32_t shift;            // first bit of the digit
     uint32_t mask;             // (1 << digit bits of this pass) - 1
     const uint8_t* digit_map;  // optional: digit = digit_map[(key >> shift) & mask]
+    // optional, with digit_map: table entries equal to kMapBySplitters send the key to a comparison
+    // with `num_splitters` ascending key values (u32 or u64 like the keys) instead:
+    // digit = 2 * #{r : key >= splitter[r]} - #{r : key == splitter[r] and bit r of exact_mask}
+    const void* splitters;
+    uint32_t num_splitters;
+    uint32_t exact_mask;
     // three-kernel: scanned block histogram, digit-major [radix][num_tiles]
     const uint32_t* scanned;
     // onesweep
@@ -110,6 +118,9 @@ struct mrs_context {
     // passes may hand consecutive tiles to workgroups of one die.
     bool workgroups_on_all_dies;
     bool die_aware_tickets;  // workgroups_on_all_dies, unless switched off (mrs_context_set_attribute)
+    int live_plans;          // plans created on this context and not yet destroyed
+    // Address, on this device, of the library's static scratch array (mrs_sort_pairs_noalloc).
+    void* static_scratch;
 };
 
 struct mrs_plan {
@@ -122,6 +133,7 @@ struct mrs_plan {
     // device memory owned by the plan
     void* temp;
     size_t temp_bytes;
+    bool owns_temp;  // temp came from hipMalloc in mrs_plan_create (false: the library's static scratch)
     // three-kernel
     uint32_t* hist;          // [radix][max_tiles]
     uint32_t* scan_partials; // chunk sums of the scan

@@ -59,7 +59,13 @@ struct StatusBits {
 };
 
 // Timing-only ablations for diagnostic builds (results are wrong when non-zero):
-// 1 = no look-back, 2 = no ranking, 4 = no payload, 8 = no global stores.
+// 1 = no look-back, 2 = no ranking, 4 = no payload, 8 = no global stores,
+// 16 = no look-back, but the tile's digit runs go where tiles of equal digit counts would put
+//      them (the scatter pattern without the chain),
+// 32 = everything computed, but the output addresses are in tile order (the chain without the
+//      scatter pattern),
+// 64 = with 32: every address one element further (sequential, but no store is line-aligned),
+// 128 = with 32: aligned 256-byte segments, each sent to a pseudo-random place of the array.
 #ifndef MRS_ABLATE
 #define MRS_ABLATE 0
 #endif
@@ -398,7 +404,7 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     const bool in_walk = MODE == kModeOnesweep && tid < RADIX;
     const uint32_t lb_digit = tid;
     const StatusT* const status = static_cast<const StatusT*>(a.status);
-    const bool walker = in_walk && !(kAblate & 1) && tile != 0;
+    const bool walker = in_walk && !(kAblate & (1 | 16)) && tile != 0;
     // of the walked digit: first output position in the whole array, count and offset in this tile
     uint32_t digit_base = 0;
     const uint32_t walk_count = tile_count, walk_off = tile_off;
@@ -460,7 +466,7 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
             resolve_round();
         }
         // tile 0 has nothing before it
-        if (in_walk && !walker) sh.gbase[lb_digit] = digit_base - walk_off;
+        if (in_walk && !walker) sh.gbase[lb_digit] = digit_base - walk_off + ((kAblate & 16) ? tile * walk_count : 0u);
         MRS_STAMP(12);
     }
     // ---- local sort of the keys through LDS ---------------------------------------
@@ -510,7 +516,13 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
             const KeyT k = stage_keys[slot];
             d = key_digit<MAP>(k, a.shift, a.mask, a.digit_map);
             uint32_t g = sh.gbase[d] + slot;
-            if (kAblate & 3) g = static_cast<uint32_t>(tile_base) + slot;
+            if (kAblate & (3 | 32)) g = static_cast<uint32_t>(tile_base) + slot;
+            if (kAblate & 16) g = g < a.n ? g : slot;  // the estimate may overshoot the last run
+            if (kAblate & 64) g = g + 1 < a.n ? g + 1 : 0;
+            if (kAblate & 128) {
+                const uint32_t chunks = a.n >> 6;  // n is a multiple of 64 in the timing runs
+                g = ((g >> 6) * 2654435761u % chunks) * 64u + (g & 63u);
+            }
             if (kAblate & 8) { keep_alive(k); keep_alive(g); }
             else store_element<OFF32>(keys_out, g, k);
         }
@@ -535,7 +547,13 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
             if (FULL || slot < tile_valid) {
                 const ValT v = stage_vals[slot];
                 uint32_t g = sh.gbase[slot_digit.get(i)] + slot;
-                if (kAblate & 3) g = static_cast<uint32_t>(tile_base) + slot;
+                if (kAblate & (3 | 32)) g = static_cast<uint32_t>(tile_base) + slot;
+                if (kAblate & 16) g = g < a.n ? g : slot;
+                if (kAblate & 64) g = g + 1 < a.n ? g + 1 : 0;
+                if (kAblate & 128) {
+                    const uint32_t chunks = a.n >> 6;
+                    g = ((g >> 6) * 2654435761u % chunks) * 64u + (g & 63u);
+                }
                 if (kAblate & 8) keep_alive(v);
                 else store_element<OFF32>(vals_out, g, v);
             }
