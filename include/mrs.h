@@ -105,6 +105,9 @@ int mrs_context_destroy(mrs_context* ctx);
 #define MRS_ATTR_DIE_AWARE_TICKETS 2 /* 1 if a large grid was seen to land on all 8 dies (XCDs) in
                                     comparable shares: onesweep passes then hand blocks of
                                     consecutive tiles to workgroups of one die               */
+#define MRS_ATTR_NOALLOC_TIMEOUT 3 /* synchronises the device; 1 if a chained-scan workgroup of an
+                                    mrs_sort_pairs_noalloc call gave up waiting since the last
+                                    query (that call's output is invalid); reading clears it     */
 int mrs_context_get_attribute(const mrs_context* ctx, int attribute, int64_t* value);
 /* MRS_ATTR_DIE_AWARE_TICKETS can be cleared (value 0) and, where the creation-time check passed,
  * set again.  With die-aware tickets a pass makes progress only if it keeps getting workgroup
@@ -210,6 +213,24 @@ int mrs_morton_encode30_for_sort(mrs_plan* plan, const float* xyz_dev, uint64_t 
  * not been written since.  mrs_sort_pairs itself never uses left-over histograms. */
 int mrs_sort_pairs_primed(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b,
                           void* vals_b, void* stream, int* result_in_b);
+
+/* mrs_sort_pairs for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference, whose every call
+ * re-creates all of its buffers (src/main.rs:382-388).  Sorts n (u32 key, u32 payload) pairs on
+ * key bits [begin_bit, end_bit) with 8-bit digits and chained-scan passes, exactly as a plan
+ * created for that n would, but takes no plan: the temporary memory (tile status words, digit
+ * histograms, ticket counters) is a static array of the library's code object, about 8 MiB that
+ * every GPU the library runs on holds from the load of the library until the process ends.  The
+ * call makes no hipMalloc/hipFree and no other allocating call; n may be at most 2^26
+ * (MRS_NOALLOC_MAX_N), larger inputs are rejected with MRS_ERR_INVALID_ARGUMENT.  All calls on
+ * one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two
+ * threads, two contexts of one device) race and give wrong results; calls that follow each
+ * other on one stream are safe, each clears what it needs.  A look-back that timed out is
+ * reported through mrs_context_get_attribute(ctx, MRS_ATTR_NOALLOC_TIMEOUT, ...). */
+#define MRS_NOALLOC_MAX_N (1ull << 26)
+int mrs_sort_pairs_noalloc(mrs_context* ctx, uint64_t n, uint32_t* keys_a, uint32_t* vals_a,
+                           uint32_t* keys_b, uint32_t* vals_b, int32_t begin_bit, int32_t end_bit,
+                           void* stream, int* result_in_b);
 
 /* Sort by key, moving each wide record once: the variant the reference's own comments
  * anticipate for TriangleIndices (src/types.rs:26-36, src/shaders/radix_sort_index.wgsl:3-6)

@@ -65,6 +65,8 @@ class Context:
     ATTR_COMPUTE_UNITS = 0
     ATTR_RANK_MODE = 1
     ATTR_DIE_AWARE_TICKETS = 2
+    ATTR_NOALLOC_TIMEOUT = 3
+    NOALLOC_MAX_N = 1 << 26
 
     def attribute(self, which):
         """`mrs_context_get_attribute`: what the context found on its device."""
@@ -131,6 +133,20 @@ class Context:
             )
         )
         return codes_out
+
+    # ---- the sort without a plan and without allocations ---------------------------
+    def sort_pairs_noalloc(self, keys_a, vals_a, keys_b, vals_b, n, begin_bit=0, end_bit=32, stream=None):
+        """`mrs_sort_pairs_noalloc`: (u32 key, u32 payload) pairs, temporary memory in the library's
+        static scratch array (n <= NOALLOC_MAX_N).  Returns True when the result is in the B tensors."""
+        for t in (keys_a, vals_a, keys_b, vals_b):
+            if t is None or _nbytes(t) < 4 * n:
+                raise ValueError("tensor is missing or too small")
+        in_b = ctypes.c_int(0)
+        _lib.check(
+            self.lib.mrs_sort_pairs_noalloc(self._h, n, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
+                                            begin_bit, end_bit, _stream(stream), ctypes.byref(in_b))
+        )
+        return bool(in_b.value)
 
     # ---- generators ----------------------------------------------------------
     def generate_points(self, seed, n, stream=None):

@@ -97,6 +97,17 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 constexpr size_t kControlBytes = (sizeof(OnesweepControl) + 255) / 256 * 256;
 
+// ---- scratch of mrs_sort_pairs_noalloc -------------------------------------------------
+// The temporary memory of a onesweep plan (error flag, control block, tile status words) for
+// inputs of at most kNoallocMaxN (u32 key, u32 payload) pairs, as one array of the code object:
+// every device the library runs on holds its own copy from the moment the code object is loaded
+// until the process ends.  2048 tiles is the most any n <= 2^26 yields (16384-key tiles below
+// 2^25 elements, 32768-key tiles from there on); 4 passes of 256 four-byte status words each.
+constexpr uint64_t kNoallocMaxN = 1ull << 26;
+constexpr size_t kNoallocStatusBytes = 2048ull * 256 * 4 * 4;
+constexpr size_t kNoallocScratchBytes = 256 + kControlBytes + kNoallocStatusBytes;
+static __device__ __align__(256) unsigned char scratch[kNoallocScratchBytes];
+
 // ---- which sorts may use die-aware tickets --------------------------------------------------
 // Two chained-scan passes that both deal their tiles per die can block each other when they run
 // at the same time (each may hold the compute units of a die the other needs a slot on), so at
@@ -356,6 +367,15 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
         int rc = MRS_OK;
         if (!(rank_env && std::strcmp(rank_env, "match") == 0)) rc = probe_lds_atomic_order(&in_order);
         if (rc == MRS_OK && prop.multiProcessorCount == 256) rc = probe_die_ids(&all_dies);
+        // This device's copy of the static scratch array.  `scratch` itself is a host-side stand-in
+        // for the symbol: only the address obtained here, with the device current, may be handed
+        // to kernels, memsets and copies.
+        if (rc == MRS_OK) {
+            hipError_t e = hipGetSymbolAddress(&scratch_ptr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !scratch_ptr)
+                rc = fail(MRS_ERR_HIP, "mrs_context_create: hipGetSymbolAddress(scratch) failed on device %d: %s",
+                          device_id, hipGetErrorString(e));
+        }
         if (rc == MRS_OK) {
             DeviceActivity& a = g_activity[device_id];
             std::lock_guard<std::mutex> lock(a.m);
@@ -390,6 +410,16 @@ extern "C" int mrs_context_get_attribute(const mrs_context* ctx, int attribute, 
         case MRS_ATTR_COMPUTE_UNITS: *value = ctx->num_cus; return MRS_OK;
         case MRS_ATTR_RANK_MODE: *value = ctx->lds_atomics_in_lane_order ? 1 : 0; return MRS_OK;
         case MRS_ATTR_DIE_AWARE_TICKETS: *value = ctx->die_aware_tickets ? 1 : 0; return MRS_OK;
+        case MRS_ATTR_NOALLOC_TIMEOUT: {
+            // the error flag is the first word of the device's static scratch array
+            if (int rc = check_device(ctx, "mrs_context_get_attribute")) return rc;
+            MRS_HIP_TRY(hipDeviceSynchronize());
+            uint32_t flag = 0;
+            MRS_HIP_TRY(hipMemcpy(&flag, ctx->static_scratch, sizeof flag, hipMemcpyDeviceToHost));
+            if (flag) MRS_HIP_TRY(hipMemset(ctx->static_scratch, 0, sizeof flag));
+            *value = flag ? 1 : 0;
+            return MRS_OK;
+        }
         default: return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_get_attribute: unknown attribute %d", attribute);
     }
 }
@@ -597,7 +627,7 @@ static int check_pair_buffers(const mrs_plan* plan, const void* ka, const void* 
     return MRS_OK;
 }
 
-// The launch schedule shared by mrs_sort_pairs and mrs_sort_pairs_primed.
+// The launch schedule shared by mrs_sort_pairs, mrs_sort_pairs_primed and mrs_sort_pairs_noalloc.
 // `primed`: the plan's control block already holds the digit histograms of exactly these keys.
 static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b,
                            hipStream_t s, int* result_in_b, bool primed, const char* who)
@@ -727,6 +757,43 @@ extern "C" int mrs_sort_pairs_primed(mrs_plan* plan, uint64_t n, void* keys_a, v
     }
     return sort_pairs_impl(plan, n, keys_a, vals_a, keys_b, vals_b, static_cast<hipStream_t>(stream), result_in_b, true,
                            "mrs_sort_pairs_primed");
+}
+
+// No counterpart among the plan-based calls allocates less: this one owns no plan at all.  The
+// temporary memory is the library's static scratch array on the context's device, bound to a
+// plan that lives on this call's stack.
+extern "C" int mrs_sort_pairs_noalloc(mrs_context* ctx, uint64_t n, uint32_t* keys_a, uint32_t* vals_a,
+                                      uint32_t* keys_b, uint32_t* vals_b, int32_t begin_bit, int32_t end_bit,
+                                      void* stream, int* result_in_b)
+{
+    clear_error();
+    if (!ctx) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_sort_pairs_noalloc: null context");
+    if (int rc = check_device(ctx, "mrs_sort_pairs_noalloc")) return rc;
+    if (n > kNoallocMaxN)
+        return fail(MRS_ERR_INVALID_ARGUMENT,
+                    "mrs_sort_pairs_noalloc: n = %llu exceeds the %llu pairs the static scratch array is sized for; "
+                    "use a plan and mrs_sort_pairs",
+                    (unsigned long long)n, (unsigned long long)kNoallocMaxN);
+    mrs_plan_desc d{};
+    d.n = n ? n : 1;
+    d.key_words = 1;
+    d.payload_bytes = 4;
+    d.digit_bits = 8;
+    d.begin_bit = begin_bit;
+    d.end_bit = end_bit;
+    d.algo = MRS_ALGO_ONESWEEP;
+    d.tile_items = 0;
+    mrs_plan plan{};
+    if (int rc = fill_plan(&plan, ctx, &d, "mrs_sort_pairs_noalloc")) return rc;
+    if (plan.status_word_bytes != 4 || onesweep_temp_bytes(&plan) > kNoallocScratchBytes)
+        return fail(MRS_ERR_UNSUPPORTED, "mrs_sort_pairs_noalloc: this tile shape needs %zu bytes of scratch, the array holds %zu",
+                    onesweep_temp_bytes(&plan), kNoallocScratchBytes);
+    if (!ctx->static_scratch) return fail(MRS_ERR_HIP, "mrs_sort_pairs_noalloc: the context has no scratch address");
+    bind_onesweep_memory(&plan, ctx->static_scratch);
+    plan.temp_bytes = kNoallocScratchBytes;
+    plan.owns_temp = false;
+    return sort_pairs_impl(&plan, n, keys_a, vals_a, keys_b, vals_b, static_cast<hipStream_t>(stream), result_in_b, false,
+                           "mrs_sort_pairs_noalloc");
 }
 
 extern "C" int mrs_plan_set_timing(mrs_plan* plan, int enable)
