@@ -68,6 +68,9 @@ extern "C" {
                           result_in_b: *mut c_int) -> c_int;
     pub fn mrs_morton_encode30_for_sort(plan: *mut mrs_plan, xyz_dev: *const f32, n: u64, mn: *const f32, mx: *const f32,
                                         keys_dev: *mut u32, idx_dev: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn mrs_sort_pairs_primed(plan: *mut mrs_plan, n: u64, keys_a: *mut c_void, vals_a: *mut c_void,
+                                 keys_b: *mut c_void, vals_b: *mut c_void, stream: *mut c_void,
+                                 result_in_b: *mut c_int) -> c_int;
     pub fn mrs_sort_pairs_noalloc(ctx: *mut mrs_context, n: u64, keys_a: *mut u32, vals_a: *mut u32, keys_b: *mut u32,
                                   vals_b: *mut u32, begin_bit: i32, end_bit: i32, stream: *mut c_void,
                                   result_in_b: *mut c_int) -> c_int;
