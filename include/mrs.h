@@ -261,6 +261,99 @@ int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, const void* v
                   const uint8_t* map_dev, uint32_t num_parts,
                   uint32_t* part_counts_dev, void* stream);
 
+/* ---- the sort sharded over the GPUs of a node ------------------------------------------
+ * No counterpart in the reference, which records everything for one device (src/main.rs:376).
+ * One rank per GPU; rank r holds a slice of the (key, payload) pairs, in rank order.  A call to
+ * mrs_dist_sort_pairs on every rank leaves rank r with the r-th slice of the globally sorted
+ * order (stable: equal keys keep the order rank 0's slice, rank 1's slice, ...):
+ *   1. histogram of the top 12 key bits of the local slice (mrs_bucket_histogram's kernel);
+ *   2. ncclAllReduce(sum) of the bucket counts -> global digit histogram, and ncclAllGather of the
+ *      per-rank rows in the same group, then ONE host round trip for both;
+ *   3. mrs_splitter (host): the key values at which the global order is cut into `world` slices.
+ *      A cut that would fall too far inside a bucket makes the splitter ask for the next digit of
+ *      that bucket's keys (one more histogram + all-gather + round trip per level; only skewed
+ *      inputs get there), and a cut inside a run of equal keys is placed by element order, so no
+ *      key distribution can overload a rank: every rank receives total/world +- 2*tolerance pairs;
+ *   4. one stable partition pass by destination (the chained-scan pass with a bucket table);
+ *   5. grouped ncclSend/ncclRecv of keys and payload (all-to-all-v over xGMI), received in source
+ *      rank order;
+ *   6. local sort of what arrived (mrs_sort_pairs).
+ * All device work is enqueued on the caller's stream. */
+typedef struct mrs_comm mrs_comm;
+typedef struct mrs_dist mrs_dist;
+
+#define MRS_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to every rank (any side channel). */
+int mrs_comm_get_unique_id(void* id_out);
+/* ncclCommInitRank on the calling thread's current device; collective over all ranks. */
+int mrs_comm_create_rccl(const void* unique_id, int32_t rank, int32_t world, mrs_comm** out);
+/* Wraps a communicator the host program already owns (an ncclComm_t); not destroyed with the handle. */
+int mrs_comm_wrap_rccl(void* nccl_comm, int32_t rank, int32_t world, mrs_comm** out);
+/* `world` ranks inside one process, one host thread per rank: collectives are device copies behind
+ * a host barrier.  Ranks may sit on different devices or share one (how the single-GPU tests run
+ * the multi-rank path).  out[0 .. world) receives one handle per rank. */
+int mrs_comm_create_local(int32_t world, mrs_comm** out);
+int mrs_comm_destroy(mrs_comm* comm);
+
+typedef struct mrs_dist_desc {
+    uint64_t n_local_max;   /* most pairs any rank passes in one call                               */
+    int32_t key_words;      /* 1 or 2, as mrs_plan_desc                                            */
+    int32_t payload_bytes;  /* 0 or 4                                                              */
+    int32_t end_bit;        /* keys are compared on bits [0, end_bit); higher bits must be zero    */
+    int32_t reserved;
+    uint64_t tolerance;     /* elements a cut may miss its ideal position by before the splitter
+                               refines it; 0 = n_local_max / 256                                   */
+} mrs_dist_desc;
+
+typedef struct mrs_dist_info {
+    uint64_t recv_capacity;   /* most pairs a rank can receive: n_local_max + 2 * tolerance + 2    */
+    uint64_t device_bytes;    /* device memory the handle owns (partition, receive and sort buffers) */
+    uint32_t last_levels;     /* histograms the splitter needed in the last call (1 = top digit only) */
+    uint32_t last_exact_cuts; /* cuts of the last call placed inside a run of equal keys           */
+    uint64_t last_n_out;
+    float last_ms[4];         /* last call with timing on: histogram + collectives + splitter,
+                                 partition, exchange, local sort                                   */
+} mrs_dist_info;
+
+int mrs_dist_create(mrs_context* ctx, mrs_comm* comm, const mrs_dist_desc* desc, mrs_dist** out);
+int mrs_dist_destroy(mrs_dist* dist);
+int mrs_dist_set_timing(mrs_dist* dist, int enable);
+int mrs_dist_get_info(mrs_dist* dist, mrs_dist_info* info);
+/* Collective.  keys_in / vals_in: this rank's n_local pairs (left untouched).  On return
+ * *keys_out / *vals_out point at this rank's slice of the sorted order inside memory the handle
+ * owns (valid until the next call on the handle) and *n_out is its length; the data is complete
+ * once `stream` has caught up.  The host blocks once (or once per splitter level) inside. */
+int mrs_dist_sort_pairs(mrs_dist* dist, uint64_t n_local, const void* keys_in, const void* vals_in,
+                        void** keys_out, void** vals_out, uint64_t* n_out, void* stream);
+/* Synchronises `stream`; MRS_ERR_DEVICE_TIMEOUT as mrs_plan_check, for both passes the call ran. */
+int mrs_dist_check(mrs_dist* dist, void* stream);
+
+/* The splitter of step 3 on its own (host only, no GPU needed): what mrs_dist_sort_pairs uses, and
+ * what a host that brings its own histograms and exchange can use. */
+typedef struct mrs_splitter mrs_splitter;
+typedef struct mrs_split_result {
+    int32_t world;
+    int32_t levels;             /* histograms consumed                                            */
+    uint64_t total;             /* pairs over all ranks                                           */
+    uint64_t rank_size[16];
+    uint64_t cut_key[15];       /* cut r lies between destinations r and r + 1: keys below
+                                   cut_key[r] go to destinations <= r                              */
+    uint32_t exact_mask;        /* bit r: keys EQUAL to cut_key[r] are split by element order     */
+    uint32_t reserved;
+    uint64_t send_count[16][16]; /* [source][destination], in the order of the source's slice
+                                    after a stable partition by destination                        */
+} mrs_split_result;
+int mrs_splitter_create(int32_t world, int32_t key_bits, uint64_t tolerance, mrs_splitter** out);
+int mrs_splitter_destroy(mrs_splitter* sp);
+/* The histogram wanted next: counts of digit (key >> *shift) & ((1 << *bits) - 1) over the keys
+ * with (key >> (*shift + *bits)) == prefixes[j], for each j < *num_prefixes (at most 15; one
+ * prefix 0 at the first level, which covers every key).  *bits == 0: all cuts are placed. */
+int mrs_splitter_next(mrs_splitter* sp, uint32_t* shift, uint32_t* bits, uint32_t* num_prefixes,
+                      uint64_t* prefixes);
+/* counts[(rank * num_prefixes + j) << bits | digit] for the histogram mrs_splitter_next described. */
+int mrs_splitter_feed(mrs_splitter* sp, const uint64_t* counts);
+int mrs_splitter_get(const mrs_splitter* sp, mrs_split_result* out);
+
 /* ---- input generator (stands in for create_scene's RNG, src/main.rs:114-161) */
 /* xyz_dev[3i+c] = top 24 bits of hash(seed, c, i) * 2^-24, uniform in [0,1). */
 int mrs_generate_points(mrs_context* ctx, uint64_t seed, uint64_t n, float* xyz_dev,

@@ -51,6 +51,28 @@ class PlanInfoStruct(ctypes.Structure):
     ]
 
 
+class DistDesc(ctypes.Structure):
+    _fields_ = [
+        ("n_local_max", ctypes.c_uint64),
+        ("key_words", ctypes.c_int32),
+        ("payload_bytes", ctypes.c_int32),
+        ("end_bit", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("tolerance", ctypes.c_uint64),
+    ]
+
+
+class DistInfoStruct(ctypes.Structure):
+    _fields_ = [
+        ("recv_capacity", ctypes.c_uint64),
+        ("device_bytes", ctypes.c_uint64),
+        ("last_levels", ctypes.c_uint32),
+        ("last_exact_cuts", ctypes.c_uint32),
+        ("last_n_out", ctypes.c_uint64),
+        ("last_ms", ctypes.c_float * 4),
+    ]
+
+
 _vp = ctypes.c_void_p
 _u64 = ctypes.c_uint64
 _u32 = ctypes.c_uint32
@@ -84,6 +106,22 @@ SIGNATURES = {
     "mrs_scatter": (ctypes.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "mrs_bucket_histogram": (ctypes.c_int, [_vp, _vp, _u64, _i32, _u32, _u32, _vp, _vp]),
     "mrs_partition": (ctypes.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _vp, _vp]),
+    "mrs_comm_get_unique_id": (ctypes.c_int, [_vp]),
+    "mrs_comm_create_rccl": (ctypes.c_int, [_vp, _i32, _i32, ctypes.POINTER(_vp)]),
+    "mrs_comm_wrap_rccl": (ctypes.c_int, [_vp, _i32, _i32, ctypes.POINTER(_vp)]),
+    "mrs_comm_create_local": (ctypes.c_int, [_i32, ctypes.POINTER(_vp)]),
+    "mrs_comm_destroy": (ctypes.c_int, [_vp]),
+    "mrs_dist_create": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(DistDesc), ctypes.POINTER(_vp)]),
+    "mrs_dist_destroy": (ctypes.c_int, [_vp]),
+    "mrs_dist_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mrs_dist_get_info": (ctypes.c_int, [_vp, ctypes.POINTER(DistInfoStruct)]),
+    "mrs_dist_sort_pairs": (ctypes.c_int, [_vp, _u64, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_u64), _vp]),
+    "mrs_dist_check": (ctypes.c_int, [_vp, _vp]),
+    "mrs_splitter_create": (ctypes.c_int, [_i32, _i32, _u64, ctypes.POINTER(_vp)]),
+    "mrs_splitter_destroy": (ctypes.c_int, [_vp]),
+    "mrs_splitter_next": (ctypes.c_int, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(_u64)]),
+    "mrs_splitter_feed": (ctypes.c_int, [_vp, _vp]),
+    "mrs_splitter_get": (ctypes.c_int, [_vp, _vp]),
     "mrs_generate_points": (ctypes.c_int, [_vp, _u64, _u64, _vp, _vp]),
     "mrs_generate_u32": (ctypes.c_int, [_vp, _u64, _u64, _u64, _vp, _vp]),
 }

@@ -964,6 +964,85 @@ extern "C" int mrs_bucket_histogram(mrs_context* ctx, const void* keys_dev, uint
     return MRS_OK;
 }
 
+namespace mrs {
+
+// The partition pass behind mrs_partition and the sharded sort.  `class_starts_dev` (u32[256],
+// may be null): the exclusive scan of the digit histogram if the caller already knows it, which
+// saves the histogram and scan launches; digits beyond the table (`splitters_dev`) need it.
+int partition_internal(mrs_plan* plan, uint64_t n, const void* keys_in, const void* vals_in, void* keys_out,
+                       void* vals_out, uint32_t shift, uint32_t bits, const uint8_t* map_dev, const void* splitters_dev,
+                       uint32_t num_splitters, uint32_t exact_mask, const uint32_t* class_starts_dev, hipStream_t s)
+{
+    // the control block is about to be overwritten: histograms an encoder left are gone, and
+    // the record of which passes the last sort left out no longer describes it
+    plan->primed_keys = nullptr;
+    plan->pass_plan_live = false;
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
+    const size_t zero =
+        kControlBytes + align_up(static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes, 256);
+    MRS_HIP_TRY(hipMemsetAsync(plan->zero_begin, 0, zero, s));
+    if (class_starts_dev) {
+        MRS_HIP_TRY(hipMemcpyAsync(plan->control->ghist, class_starts_dev, plan->radix * sizeof(uint32_t),
+                                   hipMemcpyDeviceToDevice, s));
+    } else {
+        if (num_splitters) return fail(MRS_ERR_INVALID_ARGUMENT, "partition: splitters need precomputed class offsets");
+        GlobalHistArgs h{};
+        h.keys = keys_in;
+        h.n = n32;
+        h.begin_bit = shift;
+        h.end_bit = shift + bits;
+        h.num_passes = 1;
+        h.digit_map = map_dev;
+        h.map_mask = (1u << bits) - 1u;
+        h.ghist = plan->control->ghist;
+        if (int rc = launch_global_hist(plan, h, s)) return rc;
+    }
+    return MRS_OK;
+}
+
+// second half of partition_internal: the pass itself (split so that mrs_partition can copy the
+// part sizes out between the histogram and its scan)
+int partition_pass(mrs_plan* plan, uint64_t n, const void* keys_in, const void* vals_in, void* keys_out, void* vals_out,
+                   uint32_t shift, uint32_t bits, const uint8_t* map_dev, const void* splitters_dev, uint32_t num_splitters,
+                   uint32_t exact_mask, bool scan_histogram, hipStream_t s)
+{
+    if (scan_histogram)
+        if (int rc = launch_ghist_scan(plan, 1, 0, s)) return rc;
+    PassArgs a{};
+    a.keys_in = keys_in;
+    a.vals_in = vals_in;
+    a.keys_out = keys_out;
+    a.vals_out = vals_out;
+    a.n = static_cast<uint32_t>(n);
+    a.num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
+    a.shift = shift;
+    a.mask = (1u << bits) - 1u;
+    a.digit_map = map_dev;
+    a.splitters = splitters_dev;
+    a.num_splitters = num_splitters;
+    a.exact_mask = exact_mask;
+    a.digit_base = plan->control->ghist;
+    a.status = plan->status;
+    a.wide_status = plan->status_word_bytes == 8;
+    a.tile_counter = plan->control->tile_counter[0];
+    a.xcd_block = begin_ticketed_call(plan->ctx, s);
+    a.error_flag = plan->error_flag;
+    if (int rc = launch_pass(plan, kModeOnesweep, a, s)) return rc;
+    end_ticketed_call(plan->ctx, s, a.xcd_block);
+    return MRS_OK;
+}
+
+int sort_pairs_internal(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b, hipStream_t s,
+                        int* result_in_b)
+{
+    return sort_pairs_impl(plan, n, keys_a, vals_a, keys_b, vals_b, s, result_in_b, false, "mrs_dist_sort_pairs");
+}
+
+int record_mark(mrs_plan* plan, const char* label, hipStream_t s) { return mark(plan, label, s); }
+
+}  // namespace mrs
+
 extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, const void* vals_in, void* keys_out,
                              void* vals_out, uint32_t shift, uint32_t bits, const uint8_t* map_dev, uint32_t num_parts,
                              uint32_t* part_counts_dev, void* stream)
@@ -983,48 +1062,13 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
         return MRS_OK;
     }
     if (int rc = check_pair_buffers(plan, keys_in, vals_in, keys_out, vals_out, "mrs_partition")) return rc;
-    // the control block is about to be overwritten: histograms an encoder left are gone, and
-    // the record of which passes the last sort left out no longer describes it
-    plan->primed_keys = nullptr;
-    plan->pass_plan_live = false;
-    const uint32_t n32 = static_cast<uint32_t>(n);
-    const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
-    const size_t zero =
-        kControlBytes + align_up(static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes, 256);
-    MRS_HIP_TRY(hipMemsetAsync(plan->zero_begin, 0, zero, s));
-    GlobalHistArgs h{};
-    h.keys = keys_in;
-    h.n = n32;
-    h.begin_bit = shift;
-    h.end_bit = shift + bits;
-    h.num_passes = 1;
-    h.digit_map = map_dev;
-    h.map_mask = (1u << bits) - 1u;
-    h.ghist = plan->control->ghist;
-    if (int rc = launch_global_hist(plan, h, s)) return rc;
+    if (int rc = partition_internal(plan, n, keys_in, vals_in, keys_out, vals_out, shift, bits, map_dev, nullptr, 0, 0,
+                                    nullptr, s))
+        return rc;
     if (part_counts_dev) {
         const size_t have = (plan->radix < 16 ? plan->radix : 16) * sizeof(uint32_t);
         MRS_HIP_TRY(hipMemsetAsync(part_counts_dev, 0, 16 * sizeof(uint32_t), s));
         MRS_HIP_TRY(hipMemcpyAsync(part_counts_dev, plan->control->ghist, have, hipMemcpyDeviceToDevice, s));
     }
-    if (int rc = launch_ghist_scan(plan, 1, 0, s)) return rc;
-    PassArgs a{};
-    a.keys_in = keys_in;
-    a.vals_in = vals_in;
-    a.keys_out = keys_out;
-    a.vals_out = vals_out;
-    a.n = n32;
-    a.num_tiles = num_tiles;
-    a.shift = shift;
-    a.mask = (1u << bits) - 1u;
-    a.digit_map = map_dev;
-    a.digit_base = plan->control->ghist;
-    a.status = plan->status;
-    a.wide_status = plan->status_word_bytes == 8;
-    a.tile_counter = plan->control->tile_counter[0];
-    a.xcd_block = begin_ticketed_call(plan->ctx, s);
-    a.error_flag = plan->error_flag;
-    if (int rc = launch_pass(plan, kModeOnesweep, a, s)) return rc;
-    end_ticketed_call(plan->ctx, s, a.xcd_block);
-    return MRS_OK;
+    return partition_pass(plan, n, keys_in, vals_in, keys_out, vals_out, shift, bits, map_dev, nullptr, 0, 0, true, s);
 }

@@ -1,0 +1,758 @@
+// The sort sharded over the GPUs of one node (mrs_comm_*, mrs_dist_*, include/mrs.h).
+//
+// The reference records its passes for one device (src/main.rs:376, 594-665); this is the
+// scale-out of that path: one rank per GPU, sharded by top-digit bucket.  Per call and rank:
+// histogram of the top key digit -> RCCL all-reduce of the global digit histogram plus
+// all-gather of the per-rank rows -> Splitter (host, mrs_split.hpp) -> one stable partition pass
+// by destination -> grouped ncclSend/ncclRecv (all-to-all-v over xGMI) received in source-rank
+// order -> local sort.  Because the partition and the local sort are stable and slices arrive
+// in rank order, the result equals a stable sort of the concatenated input.
+//
+// RCCL is bound at run time (dlopen) so that the library loads on hosts and in processes that
+// never shard; a second transport, a group of ranks inside one process (one host thread per
+// rank, device copies behind a host barrier), runs the same orchestration on one GPU or several.
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: every function is resolved with dlsym
+
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "mrs_internal.h"
+#include "mrs_split.hpp"
+
+namespace mrs {
+
+// ---- RCCL, bound at run time ----------------------------------------------------------------
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
+};
+
+static int load_rccl(const RcclApi** out)
+{
+    static std::mutex m;
+    static RcclApi api;
+    static bool tried = false;
+    std::lock_guard<std::mutex> lock(m);
+    if (!tried) {
+        tried = true;
+        // A process that already holds an RCCL (PyTorch ships its own) keeps using that one: the
+        // first name is the library's SONAME, which the loader resolves to the copy in memory.
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* name : names) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (api.handle) {
+#define MRS_BIND(field, symbol) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, symbol))
+            MRS_BIND(GetUniqueId, "ncclGetUniqueId");
+            MRS_BIND(CommInitRank, "ncclCommInitRank");
+            MRS_BIND(CommDestroy, "ncclCommDestroy");
+            MRS_BIND(AllReduce, "ncclAllReduce");
+            MRS_BIND(AllGather, "ncclAllGather");
+            MRS_BIND(Send, "ncclSend");
+            MRS_BIND(Recv, "ncclRecv");
+            MRS_BIND(GroupStart, "ncclGroupStart");
+            MRS_BIND(GroupEnd, "ncclGroupEnd");
+            MRS_BIND(GetErrorString, "ncclGetErrorString");
+            MRS_BIND(CommGetAsyncError, "ncclCommGetAsyncError");
+#undef MRS_BIND
+        }
+    }
+    if (!api.handle) return fail(MRS_ERR_UNSUPPORTED, "librccl.so could not be loaded: %s", dlerror());
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather || !api.Send ||
+        !api.Recv || !api.GroupStart || !api.GroupEnd || !api.GetErrorString)
+        return fail(MRS_ERR_UNSUPPORTED, "librccl.so lacks a symbol this library binds");
+    *out = &api;
+    return MRS_OK;
+}
+
+#define MRS_NCCL_TRY(api, expr)                                                                         \
+    do {                                                                                                \
+        ncclResult_t _r = (expr);                                                                       \
+        if (_r != ncclSuccess)                                                                          \
+            return ::mrs::fail(MRS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, (api)->GetErrorString(_r),  \
+                               __FILE__, __LINE__);                                                     \
+    } while (0)
+
+// The two arrays of an exchange (keys, payload); element counts and offsets are shared.
+struct ExchangeArrays {
+    const void* send[2];
+    void* recv[2];
+    size_t elem_bytes[2];
+    int count;  // 1 or 2
+};
+
+}  // namespace mrs
+
+// What the orchestration needs from a transport.  All buffers are device memory; everything is
+// enqueued on `s` (the host may block on other ranks' host threads, never on the device).
+struct mrs_comm {
+    int rank = 0, world = 1;
+    virtual ~mrs_comm() {}
+    // reduced[i] = sum over ranks of send[i] (may be null); gathered[r * count + i] = rank r's send[i]
+    virtual int allreduce_allgather_u64(const uint64_t* send, uint64_t* reduced, uint64_t* gathered, size_t count,
+                                        hipStream_t s) = 0;
+    // all-to-all-v: send_cnt[d] elements from offset send_off[d] go to rank d, which stores the
+    // slice of source r at recv_off[r] (recv_cnt[r] elements)
+    virtual int alltoallv(const mrs::ExchangeArrays& x, const uint64_t* send_off, const uint64_t* send_cnt,
+                          const uint64_t* recv_off, const uint64_t* recv_cnt, hipStream_t s) = 0;
+    // an error the transport noticed asynchronously since the last call
+    virtual int check_async() { return MRS_OK; }
+};
+
+namespace mrs {
+
+// ---- transport 1: RCCL ------------------------------------------------------------------------
+struct RcclComm final : mrs_comm {
+    const RcclApi* api = nullptr;
+    ncclComm_t comm = nullptr;
+    bool owned = false;
+    ~RcclComm() override
+    {
+        if (owned && comm) (void)api->CommDestroy(comm);
+    }
+    int allreduce_allgather_u64(const uint64_t* send, uint64_t* reduced, uint64_t* gathered, size_t count,
+                                hipStream_t s) override
+    {
+        MRS_NCCL_TRY(api, api->GroupStart());
+        if (reduced) MRS_NCCL_TRY(api, api->AllReduce(send, reduced, count, ncclUint64, ncclSum, comm, s));
+        MRS_NCCL_TRY(api, api->AllGather(send, gathered, count, ncclUint64, comm, s));
+        MRS_NCCL_TRY(api, api->GroupEnd());
+        return MRS_OK;
+    }
+    int alltoallv(const ExchangeArrays& x, const uint64_t* send_off, const uint64_t* send_cnt, const uint64_t* recv_off,
+                  const uint64_t* recv_cnt, hipStream_t s) override
+    {
+        // RCCL has no all-to-all-v: one send and one receive per peer and array, fused in a group
+        // so that they progress together; every peer pair has its own xGMI link.
+        MRS_NCCL_TRY(api, api->GroupStart());
+        for (int a = 0; a < x.count; ++a) {
+            const size_t eb = x.elem_bytes[a];
+            for (int p = 0; p < world; ++p) {
+                if (send_cnt[p])
+                    MRS_NCCL_TRY(api, api->Send(static_cast<const char*>(x.send[a]) + send_off[p] * eb, send_cnt[p] * eb,
+                                                ncclUint8, p, comm, s));
+                if (recv_cnt[p])
+                    MRS_NCCL_TRY(api, api->Recv(static_cast<char*>(x.recv[a]) + recv_off[p] * eb, recv_cnt[p] * eb,
+                                                ncclUint8, p, comm, s));
+            }
+        }
+        MRS_NCCL_TRY(api, api->GroupEnd());
+        return MRS_OK;
+    }
+    int check_async() override
+    {
+        if (!api->CommGetAsyncError) return MRS_OK;
+        ncclResult_t state = ncclSuccess;
+        MRS_NCCL_TRY(api, api->CommGetAsyncError(comm, &state));
+        if (state != ncclSuccess && state != ncclInProgress)
+            return fail(MRS_ERR_HIP, "RCCL reported an asynchronous error: %s", api->GetErrorString(state));
+        return MRS_OK;
+    }
+};
+
+// ---- transport 2: ranks inside one process ------------------------------------------------------
+// One host thread per rank.  A collective is: every rank posts its buffers and an event that
+// marks them ready on its stream, the host threads meet, every rank copies what is meant for
+// it (on its own stream, behind the owners' events), marks itself done, the threads meet again
+// and every rank makes its stream wait for the others' done marks before it may reuse a buffer.
+struct LocalGroup {
+    int world;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    int handles_alive;
+    struct Post {
+        const void* send[2] = {nullptr, nullptr};
+        const uint64_t* send_off = nullptr;
+        const uint64_t* send_cnt = nullptr;
+        hipEvent_t ready = nullptr, done = nullptr;
+    };
+    std::vector<Post> post;
+    explicit LocalGroup(int w) : world(w), handles_alive(w), post(w) {}
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        const uint64_t gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lock, [&] { return generation != gen; });
+        }
+    }
+};
+
+__global__ void sum_rows_kernel(const unsigned long long* __restrict__ rows, unsigned long long* __restrict__ out,
+                                uint32_t count, uint32_t num_rows)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    unsigned long long sum = 0;
+    for (uint32_t r = 0; r < num_rows; ++r) sum += rows[static_cast<size_t>(r) * count + i];
+    out[i] = sum;
+}
+
+struct LocalComm final : mrs_comm {
+    std::shared_ptr<LocalGroup> group;
+    ~LocalComm() override
+    {
+        LocalGroup::Post& me = group->post[rank];
+        if (me.ready) (void)hipEventDestroy(me.ready);
+        if (me.done) (void)hipEventDestroy(me.done);
+    }
+    int prepare(hipStream_t s)
+    {
+        LocalGroup::Post& me = group->post[rank];
+        if (!me.ready) MRS_HIP_TRY(hipEventCreateWithFlags(&me.ready, hipEventDisableTiming));
+        if (!me.done) MRS_HIP_TRY(hipEventCreateWithFlags(&me.done, hipEventDisableTiming));
+        MRS_HIP_TRY(hipEventRecord(me.ready, s));
+        return MRS_OK;
+    }
+    int finish(hipStream_t s)
+    {
+        MRS_HIP_TRY(hipEventRecord(group->post[rank].done, s));
+        group->barrier();
+        for (int p = 0; p < world; ++p)
+            if (p != rank) MRS_HIP_TRY(hipStreamWaitEvent(s, group->post[p].done, 0));
+        // the posts may be overwritten only after every rank has read them
+        group->barrier();
+        return MRS_OK;
+    }
+    int allreduce_allgather_u64(const uint64_t* send, uint64_t* reduced, uint64_t* gathered, size_t count,
+                                hipStream_t s) override
+    {
+        if (int rc = prepare(s)) return rc;
+        group->post[rank].send[0] = send;
+        group->barrier();
+        for (int p = 0; p < world; ++p) {
+            if (p != rank) MRS_HIP_TRY(hipStreamWaitEvent(s, group->post[p].ready, 0));
+            MRS_HIP_TRY(hipMemcpyAsync(gathered + static_cast<size_t>(p) * count, group->post[p].send[0],
+                                       count * sizeof(uint64_t), hipMemcpyDefault, s));
+        }
+        if (reduced) {
+            hipLaunchKernelGGL(sum_rows_kernel, dim3((count + 255) / 256), dim3(256), 0, s,
+                               reinterpret_cast<const unsigned long long*>(gathered),
+                               reinterpret_cast<unsigned long long*>(reduced), static_cast<uint32_t>(count),
+                               static_cast<uint32_t>(world));
+            MRS_CHECK_LAUNCH("sum_rows_kernel");
+        }
+        return finish(s);
+    }
+    int alltoallv(const ExchangeArrays& x, const uint64_t* send_off, const uint64_t* send_cnt, const uint64_t* recv_off,
+                  const uint64_t* recv_cnt, hipStream_t s) override
+    {
+        if (int rc = prepare(s)) return rc;
+        LocalGroup::Post& me = group->post[rank];
+        me.send[0] = x.send[0];
+        me.send[1] = x.count > 1 ? x.send[1] : nullptr;
+        me.send_off = send_off;
+        me.send_cnt = send_cnt;
+        group->barrier();
+        for (int p = 0; p < world; ++p) {
+            const LocalGroup::Post& src = group->post[p];
+            if (src.send_cnt[rank] != recv_cnt[p])
+                return fail(MRS_ERR_INVALID_ARGUMENT, "local exchange: rank %d sends %llu elements to rank %d, which expects %llu",
+                            p, (unsigned long long)src.send_cnt[rank], rank, (unsigned long long)recv_cnt[p]);
+            if (recv_cnt[p] == 0) continue;
+            if (p != rank) MRS_HIP_TRY(hipStreamWaitEvent(s, src.ready, 0));
+            for (int a = 0; a < x.count; ++a) {
+                const size_t eb = x.elem_bytes[a];
+                MRS_HIP_TRY(hipMemcpyAsync(static_cast<char*>(x.recv[a]) + recv_off[p] * eb,
+                                           static_cast<const char*>(src.send[a]) + src.send_off[rank] * eb,
+                                           recv_cnt[p] * eb, hipMemcpyDefault, s));
+            }
+        }
+        return finish(s);
+    }
+};
+
+// ---- digit histogram of the keys under given prefixes (splitter levels after the first) -------
+struct PrefixHistArgs {
+    const void* keys;
+    unsigned long long n;
+    uint32_t shift, bits, num_prefixes;
+    unsigned long long prefix[kSplitMaxPrefixes];
+    unsigned long long* counts;  // [num_prefixes][1 << bits], zeroed
+};
+
+// counts[j][d] = number of keys with (key >> (shift + bits)) == prefix[j] and digit d.  Only skewed
+// inputs get here, and those are the inputs whose keys pile up on one counter: a wave whose
+// matching lanes all hold the same digit adds their number from one lane.
+template <typename KeyT>
+__global__ __launch_bounds__(1024) void prefix_histogram_kernel(const PrefixHistArgs a)
+{
+    __shared__ uint32_t s_bins[kSplitMaxPrefixes * 256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t j = tid; j < a.num_prefixes * 256u; j += 1024u) s_bins[j] = 0;
+    __syncthreads();
+    const KeyT* __restrict__ keys = static_cast<const KeyT*>(a.keys);
+    const uint32_t above = a.shift + a.bits;  // below the key width: the first level never comes here
+    const uint32_t mask = (1u << a.bits) - 1u;
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 1024ull;
+    for (unsigned long long i0 = static_cast<unsigned long long>(blockIdx.x) * 1024ull + (tid - lane); i0 < a.n; i0 += stride) {
+        const unsigned long long i = i0 + lane;
+        const bool valid = i < a.n;
+        const KeyT k = valid ? keys[i] : static_cast<KeyT>(0);
+        const unsigned long long p = static_cast<unsigned long long>(k) >> above;
+        const uint32_t d = static_cast<uint32_t>(k >> a.shift) & mask;
+        for (uint32_t j = 0; j < a.num_prefixes; ++j) {
+            const bool hit = valid && p == a.prefix[j];
+            const unsigned long long m = __ballot(hit);
+            if (m == 0) continue;
+            const int first = __ffsll(static_cast<long long>(m)) - 1;
+            const uint32_t d0 = __shfl(d, first);
+            if (__ballot(hit && d != d0) == 0) {
+                if (static_cast<int>(lane) == first) atomicAdd(&s_bins[j * 256u + d0], static_cast<uint32_t>(__popcll(m)));
+            } else if (hit) {
+                atomicAdd(&s_bins[j * 256u + d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < a.num_prefixes * 256u; idx += 1024u) {
+        const uint32_t c = s_bins[idx];
+        const uint32_t j = idx >> 8, d = idx & 255u;
+        if (c && d <= mask) atomicAdd(&a.counts[(static_cast<size_t>(j) << a.bits) + d], static_cast<unsigned long long>(c));
+    }
+}
+
+static int launch_prefix_histogram(const mrs_context* ctx, int key_words, const PrefixHistArgs& a, hipStream_t s)
+{
+    unsigned long long blocks = (a.n + 4095) / 4096;
+    const unsigned long long cap = static_cast<unsigned long long>(ctx->num_cus) * 2;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    if (key_words == 1)
+        hipLaunchKernelGGL(prefix_histogram_kernel<uint32_t>, dim3(blocks), dim3(1024), 0, s, a);
+    else
+        hipLaunchKernelGGL(prefix_histogram_kernel<unsigned long long>, dim3(blocks), dim3(1024), 0, s, a);
+    MRS_CHECK_LAUNCH("prefix_histogram_kernel");
+    return MRS_OK;
+}
+
+constexpr size_t kHistWords = 4096;  // u64 counters of one rank's histogram row (12 key bits, or 15 prefixes x 256)
+static_assert(kSplitMaxPrefixes * 256 <= kHistWords && (1 << kSplitTopBits) <= kHistWords, "histogram rows share one size");
+
+// what the host hands to the partition pass, in one upload
+struct PartitionTables {
+    uint8_t map[kMaxMapEntries];
+    unsigned long long splitters[kMaxSplitters + 1];
+    uint32_t class_starts[256];
+};
+
+}  // namespace mrs
+
+struct mrs_dist {
+    mrs_context* ctx = nullptr;
+    mrs_comm* comm = nullptr;
+    mrs_dist_desc desc{};
+    uint64_t tolerance = 0, recv_capacity = 0;
+    mrs_plan* part_plan = nullptr;
+    mrs_plan* sort_plan = nullptr;
+    size_t key_bytes = 4, val_bytes = 0;
+    // device memory owned by the handle
+    char* small = nullptr;  // [hist_local][hist_global][hist_all: world rows][PartitionTables]
+    uint64_t *hist_local = nullptr, *hist_global = nullptr, *hist_all = nullptr;
+    mrs::PartitionTables* tables_dev = nullptr;
+    void *part_k = nullptr, *part_v = nullptr, *recv_k = nullptr, *recv_v = nullptr, *tmp_k = nullptr, *tmp_v = nullptr;
+    size_t device_bytes = 0;
+    // pinned host mirrors
+    uint64_t* h_hist = nullptr;  // [hist_global][hist_all]
+    mrs::PartitionTables* h_tables = nullptr;
+    // last call
+    bool timing = false;
+    hipEvent_t marks[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool marks_valid = false;
+    uint32_t last_levels = 0, last_exact_cuts = 0;
+    uint64_t last_n_out = 0;
+};
+
+using namespace mrs;
+
+extern "C" int mrs_comm_get_unique_id(void* id_out)
+{
+    clear_error();
+    if (!id_out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_comm_get_unique_id: null output");
+    const RcclApi* api = nullptr;
+    if (int rc = load_rccl(&api)) return rc;
+    static_assert(sizeof(ncclUniqueId) == MRS_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    MRS_NCCL_TRY(api, api->GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof id);
+    return MRS_OK;
+}
+
+extern "C" int mrs_comm_create_rccl(const void* unique_id, int32_t rank, int32_t world, mrs_comm** out)
+{
+    clear_error();
+    if (!unique_id || !out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_comm_create_rccl: null argument");
+    *out = nullptr;
+    if (world < 1 || world > kSplitMaxRanks || rank < 0 || rank >= world)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_comm_create_rccl: need 0 <= rank < world <= %d", kSplitMaxRanks);
+    const RcclApi* api = nullptr;
+    if (int rc = load_rccl(&api)) return rc;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    ncclComm_t comm = nullptr;
+    MRS_NCCL_TRY(api, api->CommInitRank(&comm, world, id, rank));
+    RcclComm* c = new RcclComm;
+    c->api = api;
+    c->comm = comm;
+    c->owned = true;
+    c->rank = rank;
+    c->world = world;
+    *out = c;
+    return MRS_OK;
+}
+
+extern "C" int mrs_comm_wrap_rccl(void* nccl_comm, int32_t rank, int32_t world, mrs_comm** out)
+{
+    clear_error();
+    if (!nccl_comm || !out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_comm_wrap_rccl: null argument");
+    *out = nullptr;
+    if (world < 1 || world > kSplitMaxRanks || rank < 0 || rank >= world)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_comm_wrap_rccl: need 0 <= rank < world <= %d", kSplitMaxRanks);
+    const RcclApi* api = nullptr;
+    if (int rc = load_rccl(&api)) return rc;
+    RcclComm* c = new RcclComm;
+    c->api = api;
+    c->comm = static_cast<ncclComm_t>(nccl_comm);
+    c->owned = false;
+    c->rank = rank;
+    c->world = world;
+    *out = c;
+    return MRS_OK;
+}
+
+extern "C" int mrs_comm_create_local(int32_t world, mrs_comm** out)
+{
+    clear_error();
+    if (!out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_comm_create_local: null output");
+    if (world < 1 || world > kSplitMaxRanks)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_comm_create_local: world must be in [1, %d]", kSplitMaxRanks);
+    auto group = std::make_shared<LocalGroup>(world);
+    for (int r = 0; r < world; ++r) {
+        LocalComm* c = new LocalComm;
+        c->group = group;
+        c->rank = r;
+        c->world = world;
+        out[r] = c;
+    }
+    return MRS_OK;
+}
+
+extern "C" int mrs_comm_destroy(mrs_comm* comm)
+{
+    clear_error();
+    delete comm;
+    return MRS_OK;
+}
+
+static void free_dist(mrs_dist* d)
+{
+    if (!d) return;
+    if (d->part_plan) (void)mrs_plan_destroy(d->part_plan);
+    if (d->sort_plan) (void)mrs_plan_destroy(d->sort_plan);
+    void* dev[] = {d->small, d->part_k, d->part_v, d->recv_k, d->recv_v, d->tmp_k, d->tmp_v};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    if (d->h_hist) (void)hipHostFree(d->h_hist);
+    if (d->h_tables) (void)hipHostFree(d->h_tables);
+    for (hipEvent_t e : d->marks)
+        if (e) (void)hipEventDestroy(e);
+    delete d;
+}
+
+extern "C" int mrs_dist_create(mrs_context* ctx, mrs_comm* comm, const mrs_dist_desc* desc, mrs_dist** out)
+{
+    clear_error();
+    if (!ctx || !comm || !desc || !out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_create: null argument");
+    *out = nullptr;
+    int cur = -1;
+    MRS_HIP_TRY(hipGetDevice(&cur));
+    if (cur != ctx->device)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_create: context is for device %d but the current device is %d",
+                    ctx->device, cur);
+    if (desc->key_words != 1 && desc->key_words != 2) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_create: key_words must be 1 or 2");
+    if (desc->payload_bytes != 0 && desc->payload_bytes != 4)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_create: payload_bytes must be 0 or 4");
+    if (desc->end_bit < 1 || desc->end_bit > 32 * desc->key_words)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_create: end_bit must be in [1, %d]", 32 * desc->key_words);
+    if (desc->n_local_max == 0 || desc->n_local_max >= (1ull << 31))
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_create: n_local_max must satisfy 0 < n_local_max < 2^31");
+    mrs_dist* d = new mrs_dist;
+    d->ctx = ctx;
+    d->comm = comm;
+    d->desc = *desc;
+    d->tolerance = desc->tolerance ? desc->tolerance : desc->n_local_max / 256;
+    d->recv_capacity = desc->n_local_max + 2 * d->tolerance + 2;
+    d->key_bytes = 4u * desc->key_words;
+    d->val_bytes = desc->payload_bytes;
+    if (d->recv_capacity >= 0xFFFFFFFFull) {
+        free_dist(d);
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_create: n_local_max + 2 * tolerance must stay below 2^32");
+    }
+    auto bail = [&](int rc) {
+        free_dist(d);
+        return rc;
+    };
+    // the partition runs the chained-scan pass with 8-bit digits (up to 31 key classes)
+    mrs_plan_desc pd{};
+    pd.n = desc->n_local_max;
+    pd.key_words = desc->key_words;
+    pd.payload_bytes = desc->payload_bytes;
+    pd.digit_bits = 8;
+    pd.begin_bit = 0;
+    pd.end_bit = desc->end_bit;
+    pd.algo = MRS_ALGO_ONESWEEP;
+    pd.tile_items = 0;
+    if (int rc = mrs_plan_create(ctx, &pd, &d->part_plan)) return bail(rc);
+    pd.n = d->recv_capacity;
+    if (int rc = mrs_plan_create(ctx, &pd, &d->sort_plan)) return bail(rc);
+    const size_t rows = static_cast<size_t>(comm->world) + 2;
+    const size_t small_bytes = rows * kHistWords * sizeof(uint64_t) + sizeof(PartitionTables);
+    auto dev_alloc = [&](void** p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        if (e != hipSuccess) return fail(MRS_ERR_OUT_OF_MEMORY, "mrs_dist_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        d->device_bytes += bytes;
+        return MRS_OK;
+    };
+    if (int rc = dev_alloc(reinterpret_cast<void**>(&d->small), small_bytes)) return bail(rc);
+    d->hist_local = reinterpret_cast<uint64_t*>(d->small);
+    d->hist_global = d->hist_local + kHistWords;
+    d->hist_all = d->hist_global + kHistWords;
+    d->tables_dev = reinterpret_cast<PartitionTables*>(d->hist_all + static_cast<size_t>(comm->world) * kHistWords);
+    if (int rc = dev_alloc(&d->part_k, desc->n_local_max * d->key_bytes)) return bail(rc);
+    if (int rc = dev_alloc(&d->recv_k, d->recv_capacity * d->key_bytes)) return bail(rc);
+    if (int rc = dev_alloc(&d->tmp_k, d->recv_capacity * d->key_bytes)) return bail(rc);
+    if (d->val_bytes) {
+        if (int rc = dev_alloc(&d->part_v, desc->n_local_max * d->val_bytes)) return bail(rc);
+        if (int rc = dev_alloc(&d->recv_v, d->recv_capacity * d->val_bytes)) return bail(rc);
+        if (int rc = dev_alloc(&d->tmp_v, d->recv_capacity * d->val_bytes)) return bail(rc);
+    }
+    if (hipHostMalloc(reinterpret_cast<void**>(&d->h_hist), (static_cast<size_t>(comm->world) + 1) * kHistWords * sizeof(uint64_t),
+                      hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&d->h_tables), sizeof(PartitionTables), hipHostMallocDefault) != hipSuccess)
+        return bail(fail(MRS_ERR_OUT_OF_MEMORY, "mrs_dist_create: hipHostMalloc failed"));
+    mrs_plan_info pi{};
+    (void)mrs_plan_get_info(d->part_plan, &pi);
+    d->device_bytes += pi.temp_bytes;
+    (void)mrs_plan_get_info(d->sort_plan, &pi);
+    d->device_bytes += pi.temp_bytes;
+    *out = d;
+    return MRS_OK;
+}
+
+extern "C" int mrs_dist_destroy(mrs_dist* dist)
+{
+    clear_error();
+    free_dist(dist);
+    return MRS_OK;
+}
+
+extern "C" int mrs_dist_set_timing(mrs_dist* dist, int enable)
+{
+    clear_error();
+    if (!dist) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_set_timing: null handle");
+    if (enable && !dist->marks[0])
+        for (hipEvent_t& e : dist->marks) MRS_HIP_TRY(hipEventCreate(&e));
+    dist->timing = enable != 0;
+    dist->marks_valid = false;
+    return MRS_OK;
+}
+
+extern "C" int mrs_dist_get_info(mrs_dist* dist, mrs_dist_info* info)
+{
+    clear_error();
+    if (!dist || !info) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_get_info: null argument");
+    std::memset(info, 0, sizeof *info);
+    info->recv_capacity = dist->recv_capacity;
+    info->device_bytes = dist->device_bytes;
+    info->last_levels = dist->last_levels;
+    info->last_exact_cuts = dist->last_exact_cuts;
+    info->last_n_out = dist->last_n_out;
+    if (dist->timing && dist->marks_valid) {
+        MRS_HIP_TRY(hipEventSynchronize(dist->marks[4]));
+        for (int i = 0; i < 4; ++i) MRS_HIP_TRY(hipEventElapsedTime(&info->last_ms[i], dist->marks[i], dist->marks[i + 1]));
+    }
+    return MRS_OK;
+}
+
+extern "C" int mrs_dist_check(mrs_dist* dist, void* stream)
+{
+    clear_error();
+    if (!dist) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_check: null handle");
+    if (int rc = mrs_plan_check(dist->part_plan, stream)) return rc;
+    if (int rc = mrs_plan_check(dist->sort_plan, stream)) return rc;
+    return dist->comm->check_async();
+}
+
+extern "C" int mrs_dist_sort_pairs(mrs_dist* dist, uint64_t n_local, const void* keys_in, const void* vals_in,
+                                   void** keys_out, void** vals_out, uint64_t* n_out, void* stream)
+{
+    clear_error();
+    if (!dist || !keys_out || !n_out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_sort_pairs: null argument");
+    mrs_dist* d = dist;
+    int cur = -1;
+    MRS_HIP_TRY(hipGetDevice(&cur));
+    if (cur != d->ctx->device)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_sort_pairs: context is for device %d but the current device is %d",
+                    d->ctx->device, cur);
+    // Argument errors must not leave the other ranks waiting in a collective: everything that can
+    // be wrong on one rank alone is checked here, before the first one.
+    if (n_local > d->desc.n_local_max)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_sort_pairs: n_local = %llu exceeds n_local_max = %llu",
+                    (unsigned long long)n_local, (unsigned long long)d->desc.n_local_max);
+    if (n_local && (!keys_in || (d->val_bytes && !vals_in)))
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_sort_pairs: null input buffer");
+    if (d->val_bytes && !vals_out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_sort_pairs: null vals_out");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    mrs_comm* comm = d->comm;
+    const int P = comm->world, me = comm->rank;
+    const int kw = d->desc.key_words;
+    d->marks_valid = false;
+    if (d->timing) MRS_HIP_TRY(hipEventRecord(d->marks[0], s));
+
+    // ---- 1-3. histograms, collectives, cuts -------------------------------------------------
+    Splitter sp(P, d->desc.end_bit, d->tolerance);
+    uint32_t shift = 0, bits = 0;
+    std::vector<uint64_t> prefixes;
+    uint64_t* h_global = d->h_hist;
+    uint64_t* h_all = d->h_hist + kHistWords;
+    while (sp.next(&shift, &bits, &prefixes)) {
+        const size_t count = prefixes.size() << bits;
+        const bool first = sp.levels_fed() == 0;
+        if (first) {
+            if (int rc = mrs_bucket_histogram(d->ctx, keys_in, n_local, kw, shift, bits, d->hist_local, s)) return rc;
+        } else {
+            MRS_HIP_TRY(hipMemsetAsync(d->hist_local, 0, count * sizeof(uint64_t), s));
+            PrefixHistArgs a{};
+            a.keys = keys_in;
+            a.n = n_local;
+            a.shift = shift;
+            a.bits = bits;
+            a.num_prefixes = static_cast<uint32_t>(prefixes.size());
+            for (size_t j = 0; j < prefixes.size(); ++j) a.prefix[j] = prefixes[j];
+            a.counts = reinterpret_cast<unsigned long long*>(d->hist_local);
+            if (n_local)
+                if (int rc = launch_prefix_histogram(d->ctx, kw, a, s)) return rc;
+        }
+        // the global digit histogram (all-reduce) and every rank's row (all-gather), one group
+        if (int rc = comm->allreduce_allgather_u64(d->hist_local, first ? d->hist_global : nullptr, d->hist_all, count, s))
+            return rc;
+        if (first) MRS_HIP_TRY(hipMemcpyAsync(h_global, d->hist_global, count * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        MRS_HIP_TRY(hipMemcpyAsync(h_all, d->hist_all, static_cast<size_t>(P) * count * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        MRS_HIP_TRY(hipStreamSynchronize(s));  // the host round trip of this level
+        if (first) {
+            // the two collectives must tell the same story
+            for (size_t i = 0; i < count; ++i) {
+                uint64_t sum = 0;
+                for (int r = 0; r < P; ++r) sum += h_all[static_cast<size_t>(r) * count + i];
+                if (sum != h_global[i])
+                    return fail(MRS_ERR_HIP, "mrs_dist_sort_pairs: the all-reduced histogram differs from the sum of the gathered rows at bucket %zu",
+                                i);
+            }
+            if (sp.levels_fed() == 0 && n_local != 0) {
+                uint64_t mine = 0;
+                for (size_t i = 0; i < count; ++i) mine += h_all[static_cast<size_t>(me) * count + i];
+                if (mine != n_local) return fail(MRS_ERR_HIP, "mrs_dist_sort_pairs: the local histogram counts %llu keys of %llu",
+                                                 (unsigned long long)mine, (unsigned long long)n_local);
+            }
+        }
+        if (int rc = sp.feed(h_all))
+            return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_sort_pairs: inconsistent histograms (code %d): are key bits above end_bit set?", rc);
+    }
+    d->last_levels = static_cast<uint32_t>(sp.levels_fed());
+    uint32_t exact_mask = 0;
+    for (int r = 0; r < sp.num_cuts(); ++r)
+        if (sp.exact(r)) exact_mask |= 1u << r;
+    d->last_exact_cuts = static_cast<uint32_t>(__builtin_popcount(exact_mask));
+    // every rank can see every rank's load: all fail together, before any exchange
+    for (int r = 0; r < P; ++r)
+        if (sp.recv_total(r) > d->recv_capacity)
+            return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_sort_pairs: rank %d would receive %llu pairs, above the capacity %llu "
+                                                  "(n_local_max is smaller than some rank's share of the total)",
+                        r, (unsigned long long)sp.recv_total(r), (unsigned long long)d->recv_capacity);
+    const uint64_t n_recv = sp.recv_total(me);
+    if (d->timing) MRS_HIP_TRY(hipEventRecord(d->marks[1], s));
+
+    // ---- 4. stable partition by destination --------------------------------------------------
+    const void* send_k = keys_in;
+    const void* send_v = vals_in;
+    if (P > 1 && n_local) {
+        PartitionTables* t = d->h_tables;
+        sp.bucket_table(t->map);
+        for (int r = 0; r < sp.num_cuts(); ++r) {
+            if (kw == 1) reinterpret_cast<uint32_t*>(t->splitters)[r] = static_cast<uint32_t>(sp.key(r));
+            else t->splitters[r] = sp.key(r);
+        }
+        sp.class_starts(me, t->class_starts);
+        MRS_HIP_TRY(hipMemcpyAsync(d->tables_dev, t, sizeof(PartitionTables), hipMemcpyHostToDevice, s));
+        if (int rc = partition_internal(d->part_plan, n_local, keys_in, vals_in, d->part_k, d->part_v, sp.top_shift(),
+                                        sp.top_bits(), d->tables_dev->map, d->tables_dev->splitters,
+                                        static_cast<uint32_t>(sp.num_cuts()), exact_mask, d->tables_dev->class_starts, s))
+            return rc;
+        if (int rc = partition_pass(d->part_plan, n_local, keys_in, vals_in, d->part_k, d->part_v, sp.top_shift(),
+                                    sp.top_bits(), d->tables_dev->map, d->tables_dev->splitters,
+                                    static_cast<uint32_t>(sp.num_cuts()), exact_mask, false, s))
+            return rc;
+        send_k = d->part_k;
+        send_v = d->part_v;
+    }
+    if (d->timing) MRS_HIP_TRY(hipEventRecord(d->marks[2], s));
+
+    // ---- 5. exchange, received in source-rank order ------------------------------------------
+    uint64_t send_off[kSplitMaxRanks], send_cnt[kSplitMaxRanks], recv_off[kSplitMaxRanks], recv_cnt[kSplitMaxRanks];
+    uint64_t so = 0, ro = 0;
+    for (int p = 0; p < P; ++p) {
+        send_cnt[p] = sp.send_count(me, p);
+        send_off[p] = so;
+        so += send_cnt[p];
+        recv_cnt[p] = sp.send_count(p, me);
+        recv_off[p] = ro;
+        ro += recv_cnt[p];
+    }
+    ExchangeArrays x{};
+    x.send[0] = send_k;
+    x.recv[0] = d->recv_k;
+    x.elem_bytes[0] = d->key_bytes;
+    x.count = 1;
+    if (d->val_bytes) {
+        x.send[1] = send_v;
+        x.recv[1] = d->recv_v;
+        x.elem_bytes[1] = d->val_bytes;
+        x.count = 2;
+    }
+    if (int rc = comm->alltoallv(x, send_off, send_cnt, recv_off, recv_cnt, s)) return rc;
+    if (d->timing) MRS_HIP_TRY(hipEventRecord(d->marks[3], s));
+
+    // ---- 6. local sort -------------------------------------------------------------------------
+    int in_b = 0;
+    if (int rc = sort_pairs_internal(d->sort_plan, n_recv, d->recv_k, d->recv_v, d->tmp_k, d->tmp_v, s, &in_b)) return rc;
+    if (d->timing) {
+        MRS_HIP_TRY(hipEventRecord(d->marks[4], s));
+        d->marks_valid = true;
+    }
+    *keys_out = in_b ? d->tmp_k : d->recv_k;
+    if (vals_out) *vals_out = d->val_bytes ? (in_b ? d->tmp_v : d->recv_v) : nullptr;
+    *n_out = n_recv;
+    d->last_n_out = n_recv;
+    return MRS_OK;
+}

@@ -159,6 +159,16 @@ struct mrs_plan {
 
 namespace mrs {
 
+// mrs_api.hip, for the sharded sort (mrs_dist.hip)
+int partition_internal(mrs_plan* plan, uint64_t n, const void* keys_in, const void* vals_in, void* keys_out,
+                       void* vals_out, uint32_t shift, uint32_t bits, const uint8_t* map_dev, const void* splitters_dev,
+                       uint32_t num_splitters, uint32_t exact_mask, const uint32_t* class_starts_dev, hipStream_t s);
+int partition_pass(mrs_plan* plan, uint64_t n, const void* keys_in, const void* vals_in, void* keys_out, void* vals_out,
+                   uint32_t shift, uint32_t bits, const uint8_t* map_dev, const void* splitters_dev, uint32_t num_splitters,
+                   uint32_t exact_mask, bool scan_histogram, hipStream_t s);
+int sort_pairs_internal(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b, hipStream_t s,
+                        int* result_in_b);
+
 // scan (mrs_scan.hip)
 uint64_t scan_partials_len(uint64_t len);
 int launch_exclusive_scan(uint32_t* vals, uint64_t len, uint32_t* partials, hipStream_t s);

@@ -93,12 +93,31 @@ __device__ __forceinline__ void launder(unsigned long long& x)
 // ticks of the 100 MHz constant clock a look-back may wait before giving up
 constexpr unsigned long long kSpinTimeoutTicks = 400000000ull;  // 4 s
 
-template <bool MAP, typename KeyT>
-__device__ __forceinline__ uint32_t key_digit(KeyT k, uint32_t shift, uint32_t mask,
-                                              const uint8_t* __restrict__ map)
+// Class of a key among `count` ascending splitter values: twice the number of splitters the key
+// has reached, minus one for every splitter marked in `exact_mask` that it equals, so that the
+// keys equal to such a splitter form a class of their own between their neighbours (the sharded
+// sort cuts inside that class by element order).
+template <typename KeyT>
+__device__ __forceinline__ uint32_t splitter_class(KeyT k, const KeyT* split, uint32_t count, uint32_t exact_mask)
 {
-    uint32_t d = static_cast<uint32_t>(k >> shift) & mask;
-    if constexpr (MAP) d = map[d];
+    uint32_t c = 0;
+    for (uint32_t r = 0; r < count; ++r) {
+        const KeyT v = split[r];
+        c += k >= v ? 2u : 0u;
+        c -= (k == v && ((exact_mask >> r) & 1u)) ? 1u : 0u;
+    }
+    return c;
+}
+
+template <bool MAP, typename KeyT>
+__device__ __forceinline__ uint32_t key_digit(KeyT k, const PassArgs& a)
+{
+    uint32_t d = static_cast<uint32_t>(k >> a.shift) & a.mask;
+    if constexpr (MAP) {
+        d = a.digit_map[d];
+        // buckets that hold a splitter are marked in the table: their keys are compared one by one
+        if (d == kMapBySplitters) d = splitter_class<KeyT>(k, static_cast<const KeyT*>(a.splitters), a.num_splitters, a.exact_mask);
+    }
     return d;
 }
 
@@ -316,7 +335,7 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         if (kAblate & 2) { pos.set_fresh(i, 0); continue; }
-        const uint32_t d = key_digit<MAP>(key[i], a.shift, a.mask, a.digit_map);
+        const uint32_t d = key_digit<MAP>(key[i], a);
         const bool mine = FULL || (my_first + i * 64 < tile_valid);
         if constexpr (RANK == kRankAtomic) {
             uint32_t r = 0;
@@ -476,7 +495,7 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
         uint32_t p[2] = {0, 0};
 #pragma unroll
         for (int h = 0; h < 2 && i + h < KPT; ++h) {
-            const uint32_t d = key_digit<MAP>(key[i + h], a.shift, a.mask, a.digit_map);
+            const uint32_t d = key_digit<MAP>(key[i + h], a);
             p[h] = pos.get(i + h) + sh.wave_hist[wave][d];
             if (kAblate & 2) p[h] = my_first + (i + h) * 64;
             if (FULL || my_first + (i + h) * 64 < tile_valid) stage_keys[p[h]] = key[i + h];
@@ -514,7 +533,7 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
         uint32_t d = 0;
         if (FULL || slot < tile_valid) {
             const KeyT k = stage_keys[slot];
-            d = key_digit<MAP>(k, a.shift, a.mask, a.digit_map);
+            d = key_digit<MAP>(k, a);
             uint32_t g = sh.gbase[d] + slot;
             if (kAblate & (3 | 32)) g = static_cast<uint32_t>(tile_base) + slot;
             if (kAblate & 16) g = g < a.n ? g : slot;  // the estimate may overshoot the last run
@@ -661,9 +680,13 @@ __global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) voi
         // The digit table (at most kMaxMapEntries bytes) is read three times per key: keep it in
         // LDS.  The first barrier of run_digit_pass orders these stores before any lookup.
         __shared__ uint8_t s_map[kMaxMapEntries];
+        __shared__ KeyT s_split[kMaxSplitters + 1];
         for (uint32_t j = threadIdx.x; j <= a.mask && j < kMaxMapEntries; j += THREADS) s_map[j] = a.digit_map[j];
+        if (threadIdx.x < a.num_splitters && threadIdx.x < kMaxSplitters)
+            s_split[threadIdx.x] = static_cast<const KeyT*>(a.splitters)[threadIdx.x];
         PassArgs b = a;
         b.digit_map = s_map;
+        b.splitters = s_split;
         run_digit_pass<MODE, RANK, MAP, StatusT>(b, sh);
     } else {
         run_digit_pass<MODE, RANK, MAP, StatusT>(a, sh);

@@ -2,6 +2,7 @@
 #include "mrs_split.hpp"
 
 #include <algorithm>
+#include <cstring>
 
 #include "mrs_internal.h"
 

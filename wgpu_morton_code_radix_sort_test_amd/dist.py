@@ -1,185 +1,182 @@
-"""Multi-GPU sort: shard by top-digit bucket, one process per GPU.
+"""The sort sharded over the GPUs of a node: host mirror of `mrs_comm_*` / `mrs_dist_*`.
 
-The reference is single-device; this is the scale-out of its sort.  Input is
-block-distributed (rank r holds a contiguous slice, payload = global index).
-
-  1. every rank histograms the top `split_bits` key bits of its slice;
-  2. all-reduce(sum) of the 2^split_bits u64 counts -> global digit histogram (RCCL);
-  3. every rank derives the same bucket -> rank map: contiguous bucket ranges whose
-     cumulative counts are closest to multiples of N / world;
-  4. one stable partition pass groups the local slice by destination rank;
-  5. all-to-all-v of keys and payload (counts first), received in source-rank order;
-  6. stable local sort of what arrived.  Rank r then holds the r-th slice of the
-     global order, and because steps 4-6 are stable and slices arrive in rank order
-     the global result equals a stable sort of the concatenated input.
-
-The collectives are torch.distributed calls (backend "nccl" = RCCL over xGMI on
-the GPU box, "gloo" in the CPU tests); everything local goes through a
-`LocalOps` object.  `HipLocalOps` is the product implementation (libmrs.so); the
-CPU tests substitute a checker-backed double to exercise the orchestration.
+The reference is single-device; this is the scale-out of its sort (shard by top-digit bucket).
+Everything — histograms, RCCL collectives, the splitter, partition, exchange, local sort — runs
+inside libmrs.so (`csrc/mrs_dist.hip`); this module only creates the handles and wraps the
+library-owned result memory as torch tensors.  torch.distributed is used for one thing: handing
+rank 0's RCCL unique id to the other ranks.
 """
+import ctypes
+
 import numpy as np
 import torch
-import torch.distributed as dist
+
+from . import _lib
+
+UNIQUE_ID_BYTES = 128
 
 
-def bucket_to_rank_map(global_counts, world):
-    """Deterministic bucket -> rank table from the global bucket histogram.
+class Communicator:
+    """`mrs_comm`: the transport of the sharded sort."""
 
-    Rank boundaries are placed after the bucket whose inclusive cumulative count is
-    closest to r * N / world (ties to the lower bucket); the table is monotone.
-    Returns a uint8 numpy array with one entry per bucket.
-    """
-    counts = np.asarray(global_counts, dtype=np.int64)
-    nb = counts.size
-    total = int(counts.sum())
-    cum = np.cumsum(counts)
-    cuts = []
-    for r in range(1, world):
-        target = (total * r) // world
-        j = int(np.searchsorted(cum, target, side="left"))  # first bucket with cum >= target
-        if j >= nb:
-            cut = nb
-        else:
-            below = int(cum[j - 1]) if j > 0 else 0
-            # buckets [0, j) hold `below`, buckets [0, j] hold cum[j]
-            cut = j if (target - below) <= (int(cum[j]) - target) else j + 1
-        cuts.append(cut)
-    cuts = np.maximum.accumulate(np.asarray(cuts, dtype=np.int64)) if cuts else np.zeros(0, dtype=np.int64)
-    table = np.searchsorted(cuts, np.arange(nb), side="right").astype(np.uint8)
-    return table
+    def __init__(self, handle, rank, world, lib):
+        self._h, self.rank, self.world, self.lib = handle, rank, world, lib
+
+    @classmethod
+    def rccl(cls, rank, world, group=None):
+        """One rank per process, RCCL underneath.  Collective over `group` (torch.distributed),
+        which only carries the 128-byte unique id from rank 0 to the others."""
+        import torch.distributed as dist
+
+        lib = _lib.load_library()
+        buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+        if rank == 0:
+            _lib.check(lib.mrs_comm_get_unique_id(buf))
+        if world > 1:
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            buf = ctypes.create_string_buffer(box[0], UNIQUE_ID_BYTES)
+        h = ctypes.c_void_p()
+        _lib.check(lib.mrs_comm_create_rccl(buf, rank, world, ctypes.byref(h)))
+        return cls(h, rank, world, lib)
+
+    @classmethod
+    def local(cls, world):
+        """`world` ranks inside this process (one host thread per rank must drive them)."""
+        lib = _lib.load_library()
+        arr = (ctypes.c_void_p * world)()
+        _lib.check(lib.mrs_comm_create_local(world, arr))
+        return [cls(ctypes.c_void_p(arr[r]), r, world, lib) for r in range(world)]
+
+    def close(self):
+        if self._h:
+            self.lib.mrs_comm_destroy(self._h)
+            self._h = None
 
 
-class HipLocalOps:
-    """Local stages on one MI355X through the C ABI."""
+class _DeviceView:
+    """A library-owned device buffer presented through the CUDA array interface."""
 
-    def __init__(self, ctx, capacity, key_words=1, payload_bytes=4, digit_bits=8, begin_bit=0, end_bit=None):
-        from .api import ALGO_ONESWEEP, SortPlan
+    def __init__(self, ptr, words):
+        self.__cuda_array_interface__ = {"shape": (words,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
-        self.ctx = ctx
-        self.device = ctx.device
-        self.key_words = key_words
-        self.plan = SortPlan(ctx, capacity, key_words=key_words, payload_bytes=payload_bytes, digit_bits=digit_bits,
-                             begin_bit=begin_bit, end_bit=end_bit, algo=ALGO_ONESWEEP)
 
-    def empty(self, n, words):
-        return torch.empty(max(1, n * words), dtype=torch.int32, device=self.device)
-
-    def bucket_histogram(self, keys, n, shift, bits):
-        return self.ctx.bucket_histogram(keys, n, self.key_words, shift, bits)
-
-    def partition(self, keys, vals, n, keys_out, vals_out, shift, bits, table, parts):
-        table_dev = torch.from_numpy(table).to(self.device)
-        self.plan.partition(keys, vals, keys_out, vals_out, shift, bits, table_dev, parts, n=n)
-
-    def sort(self, keys_a, vals_a, keys_b, vals_b, n):
-        in_b = self.plan.sort_pairs(keys_a, vals_a, keys_b, vals_b, n=n)
-        return (keys_b, vals_b) if in_b else (keys_a, vals_a)
-
-    def mark(self):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        return e
-
-    @staticmethod
-    def elapsed_ms(a, b):
-        torch.cuda.synchronize()
-        return a.elapsed_time(b)
+def _as_tensor(ptr, words, device):
+    if words == 0 or not ptr:
+        return torch.empty(0, dtype=torch.int32, device=device)
+    return torch.as_tensor(_DeviceView(ptr, words), device=device)
 
 
 class DistributedSorter:
-    def __init__(self, ctx, n_local, world, rank, digit_bits=8, split_bits=12, key_words=1, payload_words=1,
-                 end_bit=None, slack=1.3, ops=None, group=None):
-        if world > 16:
-            raise ValueError("at most 16 ranks (one partition pass with 16 destinations)")
-        self.world, self.rank, self.group = world, rank, group
-        self.n_local = n_local
+    """`mrs_dist`: rank `comm.rank`'s end of the sharded sort of (key, payload) pairs."""
+
+    def __init__(self, ctx, comm, n_local_max, key_words=1, payload_words=1, end_bit=None, tolerance=0):
+        self.ctx, self.comm, self.lib = ctx, comm, ctx.lib
         self.key_words, self.payload_words = key_words, payload_words
         self.end_bit = 32 * key_words if end_bit is None else end_bit
-        self.split_bits = min(split_bits, self.end_bit)
-        self.shift = self.end_bit - self.split_bits
-        self.capacity = int(n_local * slack) + 1024
-        self.ops = ops or HipLocalOps(ctx, self.capacity, key_words=key_words, payload_bytes=4 * payload_words,
-                                      digit_bits=digit_bits, end_bit=self.end_bit)
-        o = self.ops
-        self.part_k, self.part_v = o.empty(n_local, key_words), o.empty(n_local, payload_words)
-        self.recv_k, self.recv_v = o.empty(self.capacity, key_words), o.empty(self.capacity, payload_words)
-        self.tmp_k, self.tmp_v = o.empty(self.capacity, key_words), o.empty(self.capacity, payload_words)
-        self._marks = None
-        self.n_recv = 0
-        self.table = None
+        desc = _lib.DistDesc(n_local_max, key_words, 4 * payload_words, self.end_bit, 0, tolerance)
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.mrs_dist_create(ctx._h, comm._h, ctypes.byref(desc), ctypes.byref(h)))
+        self._h = h
+        self.n_local_max = n_local_max
+        self.n_out = 0
 
-    def sort(self, keys, vals, n=None):
-        """Sorts the distributed array in place of its slices; returns (keys, vals) views of
-        length self.n_recv holding this rank's slice of the global order."""
-        o, P = self.ops, self.world
-        n = self.n_local if n is None else n
-        kw, pw = self.key_words, self.payload_words
-        m0 = o.mark()
-        # 1-2. global digit histogram
-        local_counts = o.bucket_histogram(keys, n, self.shift, self.split_bits)
-        global_counts = local_counts.clone()
-        dist.all_reduce(global_counts, op=dist.ReduceOp.SUM, group=self.group)
-        # 3. bucket -> rank table (same on every rank)
-        table = bucket_to_rank_map(global_counts.cpu().numpy(), P)
-        self.table = table
-        send_counts = np.bincount(table, weights=local_counts.cpu().numpy().astype(np.float64), minlength=P)
-        send_counts = send_counts.astype(np.int64)
-        m1 = o.mark()
-        # 4. stable partition by destination
-        o.partition(keys, vals, n, self.part_k, self.part_v, self.shift, self.split_bits, table, P)
-        m2 = o.mark()
-        # 5. exchange: counts, then keys and payload, received in source-rank order
-        send_t = torch.from_numpy(send_counts).to(local_counts.device)
-        recv_t = torch.empty_like(send_t)
-        dist.all_to_all_single(recv_t, send_t, group=self.group)
-        recv_counts = recv_t.cpu().numpy()
-        n_recv = int(recv_counts.sum())
-        if n_recv > self.capacity:
-            raise RuntimeError(f"rank {self.rank}: {n_recv} elements arrive but the receive buffers hold {self.capacity}; "
-                               "the top-bit buckets are too unbalanced for this slack")
-        self.n_recv = n_recv
-        for src, dst, words in ((self.part_k, self.recv_k, kw), (self.part_v, self.recv_v, pw)):
-            dist.all_to_all_single(dst[: n_recv * words], src[: n * words],
-                                   output_split_sizes=[int(c) * words for c in recv_counts],
-                                   input_split_sizes=[int(c) * words for c in send_counts], group=self.group)
-        m3 = o.mark()
-        # 6. local sort
-        out_k, out_v = o.sort(self.recv_k, self.recv_v, self.tmp_k, self.tmp_v, n_recv)
-        m4 = o.mark()
-        self._marks = (m0, m1, m2, m3, m4)
-        return out_k[: n_recv * kw], out_v[: n_recv * pw]
+    def close(self):
+        if self._h:
+            self.lib.mrs_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        raw = _lib.DistInfoStruct()
+        _lib.check(self.lib.mrs_dist_get_info(self._h, ctypes.byref(raw)))
+        return raw
+
+    def set_timing(self, enable=True):
+        _lib.check(self.lib.mrs_dist_set_timing(self._h, 1 if enable else 0))
+
+    def sort(self, keys, vals, n=None, stream=None):
+        """Collective.  Returns (keys, vals) tensors (views of memory the library owns, valid until
+        the next call) holding this rank's slice of the global order; `self.n_out` is its length."""
+        n = (keys.numel() // self.key_words) if n is None else n
+        if stream is None:
+            stream = torch.cuda.current_stream()
+        ko, vo, n_out = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+        kp = ctypes.c_void_p(keys.data_ptr()) if n else None
+        vp = ctypes.c_void_p(vals.data_ptr()) if (n and self.payload_words) else None
+        _lib.check(self.lib.mrs_dist_sort_pairs(self._h, n, kp, vp, ctypes.byref(ko), ctypes.byref(vo),
+                                                ctypes.byref(n_out), ctypes.c_void_p(stream.cuda_stream)))
+        self.n_out = int(n_out.value)
+        dev = self.ctx.device
+        out_k = _as_tensor(ko.value, self.n_out * self.key_words, dev)
+        out_v = _as_tensor(vo.value, self.n_out * self.payload_words, dev) if self.payload_words else None
+        return out_k, out_v
+
+    def check(self, stream=None):
+        if stream is None:
+            stream = torch.cuda.current_stream()
+        _lib.check(self.lib.mrs_dist_check(self._h, ctypes.c_void_p(stream.cuda_stream)))
 
     def last_breakdown(self):
-        """Phase times of the last sort() on this rank, in milliseconds."""
-        if not self._marks:
-            return {}
-        m, e = self._marks, self.ops.elapsed_ms
+        """Phase times of the last sort() on this rank in milliseconds (timing must be on)."""
+        i = self.info()
         return {
-            "dist_histogram_allreduce_ms": e(m[0], m[1]),
-            "dist_partition_ms": e(m[1], m[2]),
-            "dist_exchange_ms": e(m[2], m[3]),
-            "dist_local_sort_ms": e(m[3], m[4]),
-            "dist_recv_pairs_rank0": self.n_recv,
+            "dist_histogram_collectives_split_ms": float(i.last_ms[0]),
+            "dist_partition_ms": float(i.last_ms[1]),
+            "dist_exchange_ms": float(i.last_ms[2]),
+            "dist_local_sort_ms": float(i.last_ms[3]),
+            "dist_recv_pairs_rank0": int(i.last_n_out),
+            "dist_splitter_levels": int(i.last_levels),
+            "dist_exact_cuts": int(i.last_exact_cuts),
         }
 
-    def verify(self, out_k, out_v):
-        """Global checks without gathering the data: slices sorted, slice boundaries ordered,
-        element count and key checksum conserved.  32-bit keys only."""
-        k = out_k.to(torch.int64) & 0xFFFFFFFF
-        ok = bool((k[1:] >= k[:-1]).all()) if k.numel() > 1 else True
-        first = int(k[0]) if k.numel() else -1
-        last = int(k[-1]) if k.numel() else -1
-        info = torch.tensor([first, last, k.numel(), int(k.sum()), int(ok)], dtype=torch.int64, device=out_k.device)
-        gathered = [torch.empty_like(info) for _ in range(self.world)]
-        dist.all_gather(gathered, info, group=self.group)
+
+def pair_checksum(keys, vals):
+    """Order-independent 64-bit checksum of (key, payload) pairs (32-bit keys), on the device."""
+    k = keys.to(torch.int64) & 0xFFFFFFFF
+    v = vals.to(torch.int64) & 0xFFFFFFFF
+    h = (k * 0x9E3779B1 + v * 0x85EBCA77 + ((k << 32) ^ v) * 0x27D4EB2F) ^ (k * v)
+    return int(h.sum())  # int64 arithmetic wraps: a sum modulo 2^64
+
+
+def verify_distributed(out_k, out_v, checksum_in, n_in, group=None):
+    """Global checks without gathering the data (32-bit keys, payload = global element index,
+    collective): every slice sorted with ties in payload order, slice boundaries ordered the same
+    way, element count conserved and the multiset of (key, payload) pairs conserved (checksum)."""
+    import torch.distributed as dist
+
+    k = out_k.to(torch.int64) & 0xFFFFFFFF
+    v = out_v.to(torch.int64) & 0xFFFFFFFF
+    ok = True
+    if k.numel() > 1:
+        dk = k[1:] - k[:-1]
+        ok = bool(((dk > 0) | ((dk == 0) & (v[1:] > v[:-1]))).all())
+    first = (int(k[0]), int(v[0])) if k.numel() else (-1, -1)
+    last = (int(k[-1]), int(v[-1])) if k.numel() else (-1, -1)
+    wrap = lambda x: x - (1 << 64) if x >= (1 << 63) else x
+    info = torch.tensor([first[0], first[1], last[0], last[1], k.numel(), wrap(pair_checksum(out_k, out_v) % (1 << 64)),
+                         wrap(checksum_in % (1 << 64)), n_in, int(ok)], dtype=torch.int64, device=out_k.device)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        gathered = [torch.empty_like(info) for _ in range(world)]
+        dist.all_gather(gathered, info, group=group)
         rows = [g.cpu().numpy() for g in gathered]
-        good = all(int(r[4]) == 1 for r in rows)
-        prev_last = -1
-        for r in rows:
-            if int(r[2]) == 0:
-                continue
-            good = good and prev_last <= int(r[0])
-            prev_last = int(r[1])
-        good = good and sum(int(r[2]) for r in rows) == self.n_local * self.world
-        return good
+    else:
+        rows = [info.cpu().numpy()]
+    good = all(int(r[8]) == 1 for r in rows)
+    prev = None
+    for r in rows:
+        if int(r[4]) == 0:
+            continue
+        if prev is not None:
+            good = good and (prev < (int(r[0]), int(r[1])))
+        prev = (int(r[2]), int(r[3]))
+    good = good and sum(int(r[4]) for r in rows) == sum(int(r[7]) for r in rows)
+    mask = (1 << 64) - 1
+    good = good and (sum(int(r[5]) for r in rows) & mask) == (sum(int(r[6]) for r in rows) & mask)
+    return good
