@@ -12,13 +12,15 @@ re-sorting sorted data would be a different workload), so the timed region
 holds nothing but the K sorts.
 
 With N > 1 (launched by torch.distributed.run, one rank per GPU) a step is the
-distributed sort of N * 2^28 pairs: top-bits histogram, RCCL all-reduce, bucket
--> rank split, local partition, all-to-all-v exchange over xGMI, local sort.
+sharded sort of N * 2^28 pairs, one mrs_dist_sort_pairs call per rank: top-digit
+histogram, RCCL all-reduce + all-gather, splitter, local partition pass,
+all-to-all-v exchange over xGMI, local sort (weak scaling: 2^31 pairs at N = 8).
 
 Rank 0 prints one JSON line.  `value` is whole-job Gkeys/s.  `roofline` is for
 the dominant kernel (one onesweep digit pass: 16 algorithmic bytes per pair per
-launch) timed with HIP events on the launch stream; `cpu_baseline` is std::sort
-on a bounded sample on the host cores (N = 1 only).
+launch) timed with HIP events on the launch stream; `cpu_baseline` is
+__gnu_parallel::sort of the whole step input on the host cores (N = 1 only);
+`c4` is the same sort at 2^30 pairs (N = 1 only, when memory allows).
 """
 import argparse
 import json
@@ -51,8 +53,9 @@ def parse_args():
     ap.add_argument("--tile-items", type=int, default=0)
     ap.add_argument("--pool", type=int, default=0, help="distinct unsorted inputs (0 = steps + warmup, capped by memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log2", type=int, default=25)
+    ap.add_argument("--cpu-sample-log2", type=int, default=0, help="pairs of the parallel CPU sort = 2^this (0 = the whole step input)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the 2^30-pair leg")
     return ap.parse_args()
 
 
@@ -79,7 +82,7 @@ def verify_sorted(keys, idx, ref_keys_unsorted):
     return ok_sorted and ok_stable and ok_perm
 
 
-def cpu_baseline(sample_keys, sample_idx):
+def cpu_baseline(sample_keys, sample_idx, whole):
     """std::sort on the host (oracle/cpu_sort.cpp): single thread and all usable cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
@@ -90,7 +93,7 @@ def cpu_baseline(sample_keys, sample_idx):
     n = sample_keys.size
     k1, i1 = sample_keys.copy(), sample_idx.copy()
     secs_par, used = cs.sort_pairs(k1, i1, threads)
-    n_single = max(1, n // 4)
+    n_single = max(1, min(n // 4, 1 << 23))
     k2, i2 = sample_keys[:n_single].copy(), sample_idx[:n_single].copy()
     secs_one, _ = cs.sort_pairs(k2, i2, 1)
     return {
@@ -98,11 +101,51 @@ def cpu_baseline(sample_keys, sample_idx):
         "unit": "Gkeys/s",
         "cores": used,
         "kind": "port",
-        "sample": f"std::sort (__gnu_parallel, {used} threads) of the first 2^{int(np.log2(n))} (key,index) pairs of the "
+        "sample": f"std::sort (__gnu_parallel, {used} threads) of {'all' if whole else 'the first'} 2^{int(np.log2(n))} (key,index) pairs of the "
                   f"step input, packed as u64; single-thread std::sort on 2^{int(np.log2(n_single))} pairs: "
                   f"{n_single / secs_one / 1e9:.4f} Gkeys/s; host reports {hw} hardware threads",
         "single_thread_gkeys_per_s": n_single / secs_one / 1e9,
     }, k1, i1
+
+
+def c4_leg(ctx, log2n=30, sorts=3):
+    """The 2^30-pair configuration: 64-bit tile status words and offsets; HIP events of the library
+    around every launch.  Returns None when the device is short of memory."""
+    n = 1 << log2n
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 44 * n:  # points 12 B + pairs 8 B x 3 (input, pristine copy, ping-pong) + slack
+        return None
+    xyz = ctx.generate_points(SEED + 30, n)
+    keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+    del xyz
+    pk, pi = keys.clone(), idx.clone()
+    kb, vb = torch.empty_like(keys), torch.empty_like(idx)
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, algo=mrs.ALGO_ONESWEEP)
+    plan.set_timing(True)
+    totals, passes = [], []
+    for j in range(sorts + 1):
+        keys.copy_(pk)
+        idx.copy_(pi)
+        plan.sort_pairs(keys, idx, kb, vb)
+        tm = plan.timings()
+        if j:  # the first sort warms up
+            totals.append(sum(ms for _, ms in tm))
+            passes = [ms for lab, ms in tm if lab == "onesweep_pass"]
+    plan.check()
+    ok = verify_sorted(keys, idx, pk)
+    plan.close()
+    ms = float(np.mean(totals))
+    return {
+        "pairs": n,
+        "ms_per_sort": round(ms, 4),
+        "gkeys_per_s": n / (ms * 1e-3) / 1e9,
+        "frac_68B": SORT_BYTES_PER_PAIR * n / (ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
+        "per_pass_ms": [round(float(x), 4) for x in passes],
+        "pass_frac_16B": PASS_BYTES_PER_PAIR * n / (float(np.mean(passes)) * 1e-3) / HBM_PEAK_BYTES_PER_S,
+        "tile_status_words": "64-bit",
+        "timing": "HIP events recorded by the library around every launch of 3 sorts after 1 warm-up",
+        "verified": bool(ok),
+    }
 
 
 def load_traffic():
@@ -127,9 +170,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the sort has no CPU path")
     torch.cuda.set_device(local_rank)
-    if distributed:
-        import torch.distributed as dist
+    import torch.distributed as dist
 
+    if world > 1:
+        # torch.distributed carries the RCCL unique id to the ranks, the barriers and the max over
+        # ranks of the elapsed time; the sort's own collectives are RCCL calls inside libmrs.so
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = mrs.Context(local_rank)
@@ -144,13 +189,21 @@ def main():
     pool = max(1, min(pool, max(1, budget // per_input)))
 
     if distributed:
-        from wgpu_morton_code_radix_sort_test_amd.dist import DistributedSorter
+        from wgpu_morton_code_radix_sort_test_amd.dist import (Communicator, DistributedSorter, pair_checksum,
+                                                               verify_distributed)
 
-        sorter = DistributedSorter(ctx, n, world, rank, digit_bits=args.digit_bits)
-        inputs = [make_input(ctx, n, SEED + 1000 * rank + j) for j in range(pool)]
-        # payload = global index
-        for k, i in inputs:
-            i += rank * n
+        comm = Communicator.rccl(rank, world)
+        # the keys are 30-bit Morton codes: all 4096 buckets of the top digit are live
+        sorter = DistributedSorter(ctx, comm, n, key_words=1, payload_words=1, end_bit=30)
+        # every rank shares the scene bounds, so that the key ranges of the slices overlap fully
+        inputs = []
+        for j in range(pool):
+            xyz = ctx.generate_points(SEED + 1000 * rank + j, n)
+            k, i = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+            del xyz
+            i += rank * n  # payload = global index
+            inputs.append((k, i))
+        restore = False
 
         def step(j):
             k, i = inputs[j % pool]
@@ -175,7 +228,7 @@ def main():
             return (kb, vb) if in_b else (k, i)
 
     def barrier():
-        if distributed:
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -187,7 +240,7 @@ def main():
         out = step(j)
     barrier()
     elapsed = time.perf_counter() - t0
-    if distributed:
+    if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -207,7 +260,9 @@ def main():
         if not verified:
             raise SystemExit("bench.py: the sorted output failed verification")
     elif distributed and not args.no_verify:
-        verified = sorter.verify(out[0], out[1])
+        sorter.check()
+        k_in, i_in = inputs[(total_steps - 1) % pool]
+        verified = verify_distributed(out[0], out[1], pair_checksum(k_in, i_in), n)
         if not verified:
             raise SystemExit("bench.py: the distributed output failed verification")
 
@@ -237,6 +292,9 @@ def main():
             "unit": "GB/s",
             "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S,
             "traffic": traffic.get("bytes_per_launch") if traffic else None,
+            "traffic_source": (f"profiles/traffic.json: builder-side rocprofv3 --pmc runs (FETCH_SIZE doubled as the gfx950 "
+                               f"guide prescribes, WRITE_SIZE), {traffic.get('measured', 'date unknown')}; not measured in this run")
+            if traffic else None,
             "algorithmic_bytes_per_launch": PASS_BYTES_PER_PAIR * n,
             "avg_launch_ms": avg_pass * 1e3,
         }
@@ -281,43 +339,54 @@ def main():
             extra[label] = round(float(np.median(times[1:])), 4)
         del xyz, ek, ei
 
+    breakdown = {}
     if distributed:
         # the same roofline object at N > 1: digit passes of rank 0's local sort, HIP events on
-        # the launch stream (one extra, untimed sort of the last input)
-        try:
-            lp = sorter.ops.plan
-            lp.set_timing(True)
-            k, i = inputs[(total_steps - 1) % pool]
-            sorter.sort(k, i)
-            torch.cuda.synchronize()
-            pass_ms = [ms for lab, ms in lp.timings() if lab == "onesweep_pass"]
-            lp.set_timing(False)
-            if pass_ms and rank == 0:
-                avg_pass = float(np.mean(pass_ms)) * 1e-3
-                achieved = PASS_BYTES_PER_PAIR * sorter.n_recv / avg_pass / 1e9
-                roofline = {
-                    "bound": "hbm",
-                    "kernel": "digit_pass_kernel<onesweep> (local sort of rank 0)",
-                    "achieved": achieved,
-                    "peak": HBM_PEAK_BYTES_PER_S / 1e9,
-                    "unit": "GB/s",
-                    "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S,
-                    "traffic": None,
-                    "algorithmic_bytes_per_launch": PASS_BYTES_PER_PAIR * sorter.n_recv,
-                    "avg_launch_ms": avg_pass * 1e3,
-                }
-        except Exception as exc:  # the measurement is an extra; the throughput line stands without it
-            extra["roofline_error"] = str(exc)
-        dist.barrier()
+        # the launch stream (one extra, untimed sort of the last input; collective, so every rank runs it)
+        sorter.set_timing(True)
+        k, i = inputs[(total_steps - 1) % pool]
+        sorter.sort(k, i)
+        torch.cuda.synchronize()
+        breakdown = sorter.last_breakdown()
+        sorter.set_timing(False)
+        if breakdown.get("dist_local_sort_passes") and rank == 0:
+            avg_pass = breakdown["dist_local_sort_pass_ms"] * 1e-3
+            achieved = PASS_BYTES_PER_PAIR * sorter.n_out / avg_pass / 1e9
+            roofline = {
+                "bound": "hbm",
+                "kernel": "digit_pass_kernel<onesweep> (local sort of rank 0)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_BYTES_PER_S / 1e9,
+                "unit": "GB/s",
+                "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": PASS_BYTES_PER_PAIR * sorter.n_out,
+                "avg_launch_ms": avg_pass * 1e3,
+            }
+        if world > 1:
+            dist.barrier()
 
     cpu = None
     if rank == 0 and not distributed and not args.no_cpu_baseline:
-        m = min(n, 1 << args.cpu_sample_log2)
+        m = n if args.cpu_sample_log2 == 0 else min(n, 1 << args.cpu_sample_log2)
         sk, si = make_input(ctx, n, SEED + ((total_steps - 1) % pool)) if not (restore and total_steps > pool) \
             else pristine[0]
         sample_k = sk[:m].cpu().numpy().view(np.uint32)
         sample_i = si[:m].cpu().numpy().view(np.uint32)
-        cpu, _, _ = cpu_baseline(sample_k, sample_i)
+        del sk, si
+        cpu, _, _ = cpu_baseline(sample_k, sample_i, m == n)
+
+    c4 = None
+    if rank == 0 and not distributed and not args.no_c4 and algo == mrs.ALGO_ONESWEEP and args.log2n == 28:
+        # free the pool first: the 2^30 leg wants about 45 GiB
+        del inputs, kb, vb, out
+        if restore:
+            del pristine
+        torch.cuda.empty_cache()
+        try:
+            c4 = c4_leg(ctx)
+        except Exception as exc:  # an extra: the headline line stands without it
+            c4 = {"error": str(exc)}
 
     if rank == 0:
         line = {
@@ -341,18 +410,22 @@ def main():
                 "digit_bits": args.digit_bits,
                 "algo": args.algo,
                 "distinct_inputs": pool,
-                "parallelism": f"{world} x MI355X, sharded by top-digit bucket" if distributed else "1 x MI355X",
+                "parallelism": f"{world} x MI355X, sharded by top-digit bucket (mrs_dist_sort_pairs over RCCL)" if distributed else "1 x MI355X",
             },
             "verified": verified,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         line.update(extra)
-        if distributed:
-            line.update(sorter.last_breakdown())
+        if c4 is not None:
+            line["c4"] = c4
+        line.update(breakdown)
         print(json.dumps(line))
     if distributed:
-        dist.destroy_process_group()
+        sorter.close()
+        comm.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

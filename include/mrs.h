@@ -313,6 +313,9 @@ typedef struct mrs_dist_info {
     uint64_t last_n_out;
     float last_ms[4];         /* last call with timing on: histogram + collectives + splitter,
                                  partition, exchange, local sort                                   */
+    float last_sort_pass_ms;  /* last call with timing on: mean duration of one digit pass of the
+                                 local sort (HIP events on the launch stream)                      */
+    uint32_t last_sort_passes;
 } mrs_dist_info;
 
 int mrs_dist_create(mrs_context* ctx, mrs_comm* comm, const mrs_dist_desc* desc, mrs_dist** out);

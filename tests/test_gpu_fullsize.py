@@ -114,29 +114,103 @@ def test_full_size_head_matches_oracle(ctx, mrs, oracle):
     assert np.array_equal(rk, hk[: 1 << 22][np.argsort(hk[: 1 << 22], kind="stable")])
 
 
-def test_distributed_sorter_single_rank(ctx, mrs, oracle):
-    """The multi-GPU driver end to end on one rank: HIP histogram, partition and sort, RCCL collectives."""
-    import torch.distributed as dist
-    from gpu_util import to_u32
-    from wgpu_morton_code_radix_sort_test_amd.dist import DistributedSorter
+def _props(keys_in, idx_in, ok, ov):
+    """Size-independent checks on the device: sorted, ties in payload order, a permutation whose
+    gathered input keys equal the output keys."""
+    k = ok.to(torch.int64) & 0xFFFFFFFF
+    v = ov.to(torch.int64) & 0xFFFFFFFF
+    dk = k[1:] - k[:-1]
+    assert bool((dk >= 0).all()), "not sorted"
+    assert bool(((dk > 0) | (v[1:] > v[:-1])).all()), "ties out of order"
+    assert bool((keys_in[v] == ok).all()), "payload does not point at its key"
+    assert int(v.sum()) == ok.numel() * (ok.numel() - 1) // 2, "payload is not a permutation"
 
-    created = False
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 1000))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=ctx.device)
-        created = True
-    try:
-        n = 1 << 20
+
+@pytest.mark.parametrize("dist_name", ["morton30", "all_equal", "one_hot_bucket"])
+def test_sharded_sort_one_rccl_rank_full_size(ctx, mrs, dist_name):
+    """mrs_dist_sort_pairs over RCCL with one rank at the per-GPU size of the 8-GPU configuration
+    (2^28 pairs): ncclAllReduce / ncclAllGather of the histogram, grouped self send/receive, local sort."""
+    from wgpu_morton_code_radix_sort_test_amd.dist import Communicator, DistributedSorter
+
+    n = 1 << 28
+    if dist_name == "morton30":
         xyz = ctx.generate_points(5, n)
         keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
-        hk, hi = to_u32(keys).copy(), to_u32(idx).copy()
-        sorter = DistributedSorter(ctx, n, 1, 0)
-        ok, ov = sorter.sort(keys, idx)
-        assert sorter.verify(ok, ov)
-        order = np.argsort(hk, kind="stable")
-        assert np.array_equal(to_u32(ok), hk[order]) and np.array_equal(to_u32(ov), hi[order])
-        assert set(sorter.last_breakdown()) >= {"dist_exchange_ms", "dist_local_sort_ms"}
-    finally:
-        if created:
-            dist.destroy_process_group()
+        del xyz
+    else:
+        keys = ctx.generate_u32(3, 1, n)
+        if dist_name == "all_equal":
+            keys.fill_(0x1234567)
+        else:  # every key inside ONE of the 4096 top-digit buckets (bits 29..18 fixed)
+            keys &= 0x3FFFF
+            keys |= 0x3A500000
+        idx = torch.arange(n, dtype=torch.int32, device=ctx.device)
+    comm = Communicator.rccl(0, 1)
+    sorter = DistributedSorter(ctx, comm, n, end_bit=30)
+    ok, ov = sorter.sort(keys, idx)
+    sorter.check()
+    assert sorter.n_out == n
+    _props(keys, idx, ok, ov)
+    sorter.close()
+    comm.close()
+
+
+@pytest.mark.parametrize("dist_name", ["morton30", "all_equal", "one_hot_bucket"])
+def test_sharded_sort_two_ranks_on_one_gpu_large(ctx, mrs, dist_name):
+    """Two in-process ranks of 2^26 pairs each share the GPU: the partition pass, the splitter's
+    deeper levels (skewed inputs) and the exchange layout at a size where every kernel runs many
+    tiles.  Checked through the properties of a global stable sort."""
+    import threading
+
+    from wgpu_morton_code_radix_sort_test_amd.dist import Communicator, DistributedSorter
+
+    world, n = 2, 1 << 26
+    comms = Communicator.local(world)
+    outs, ins, errors = [None] * world, [None] * world, []
+
+    def body(r):
+        try:
+            torch.cuda.set_device(0)
+            c = mrs.Context(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                if dist_name == "morton30":
+                    xyz = c.generate_points(5 + r, n, stream=stream)
+                    keys, _ = c.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], stream=stream)
+                    del xyz
+                else:
+                    keys = c.generate_u32(3 + r, 1, n, stream=stream)
+                    if dist_name == "all_equal":
+                        keys.fill_(0x1234567)
+                    else:
+                        keys &= 0x3FFFF
+                        keys |= 0x3A500000
+                idx = torch.arange(r * n, (r + 1) * n, dtype=torch.int32, device=c.device)
+                sorter = DistributedSorter(c, comms[r], n, end_bit=30)
+                ok, ov = sorter.sort(keys, idx, stream=stream)
+                sorter.check(stream=stream)
+                stream.synchronize()
+                outs[r] = (ok.clone(), ov.clone(), sorter.info())
+                ins[r] = keys
+                sorter.close()
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    [c.close() for c in comms]
+    if errors:
+        raise errors[0]
+    all_in = torch.cat(ins)
+    ok = torch.cat([o[0] for o in outs])
+    ov = torch.cat([o[1] for o in outs])
+    assert ok.numel() == world * n
+    _props(all_in, None, ok, ov)
+    tol = n // 256
+    for o in outs:
+        assert abs(o[0].numel() - n) <= 2 * tol + 1
+    if dist_name == "all_equal":
+        assert all(o[2].last_exact_cuts == 1 for o in outs) and outs[0][0].numel() == n
+    if dist_name == "one_hot_bucket":
+        assert all(o[2].last_levels >= 2 for o in outs)

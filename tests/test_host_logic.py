@@ -8,7 +8,6 @@ import numpy as np
 import pytest
 
 from wgpu_morton_code_radix_sort_test_amd import _lib, scene
-from wgpu_morton_code_radix_sort_test_amd.dist import bucket_to_rank_map
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -101,31 +100,6 @@ def test_library_reports_errors_without_a_gpu():
     assert b"null" in lib.mrs_last_error_string()
     assert lib.mrs_context_create(0, None) == _lib.MRS_ERR_INVALID_ARGUMENT
     assert lib.mrs_sort_pairs(None, 0, None, None, None, None, None, None) == _lib.MRS_ERR_INVALID_ARGUMENT
-
-
-def test_bucket_to_rank_map():
-    counts = np.zeros(4096, dtype=np.int64)
-    counts[:1024] = 100  # Morton keys below 2^30: only the low quarter of the top-12-bit buckets is used
-    for world in (1, 2, 4, 8):
-        table = bucket_to_rank_map(counts, world)
-        assert table.dtype == np.uint8 and table.size == 4096
-        assert np.all(np.diff(table.astype(np.int64)) >= 0) and table.max() <= world - 1
-        per_rank = np.bincount(table, weights=counts, minlength=world)
-        assert np.all(per_rank == counts.sum() / world)
-    # skewed histogram: the split stays within one bucket of the ideal
-    rng = np.random.default_rng(1)
-    counts = rng.integers(0, 1000, size=4096).astype(np.int64)
-    counts[77] = 200000
-    table = bucket_to_rank_map(counts, 8)
-    per_rank = np.bincount(table, weights=counts, minlength=8)
-    ideal = counts.sum() / 8
-    assert np.all(np.diff(table.astype(np.int64)) >= 0)
-    assert np.abs(per_rank - ideal).max() <= 200000
-    # everything in one bucket: one rank takes it all
-    counts = np.zeros(256, dtype=np.int64)
-    counts[9] = 5
-    table = bucket_to_rank_map(counts, 4)
-    assert np.bincount(table, weights=counts, minlength=4).max() == 5
 
 
 # ---- the reference's random stream (ChaCha8Rng::seed_from_u64), restated ----------------------------

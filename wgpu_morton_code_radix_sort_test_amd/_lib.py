@@ -70,6 +70,8 @@ class DistInfoStruct(ctypes.Structure):
         ("last_exact_cuts", ctypes.c_uint32),
         ("last_n_out", ctypes.c_uint64),
         ("last_ms", ctypes.c_float * 4),
+        ("last_sort_pass_ms", ctypes.c_float),
+        ("last_sort_passes", ctypes.c_uint32),
     ]
 
 

@@ -575,7 +575,7 @@ extern "C" int mrs_dist_set_timing(mrs_dist* dist, int enable)
         for (hipEvent_t& e : dist->marks) MRS_HIP_TRY(hipEventCreate(&e));
     dist->timing = enable != 0;
     dist->marks_valid = false;
-    return MRS_OK;
+    return mrs_plan_set_timing(dist->sort_plan, enable);
 }
 
 extern "C" int mrs_dist_get_info(mrs_dist* dist, mrs_dist_info* info)
@@ -591,6 +591,19 @@ extern "C" int mrs_dist_get_info(mrs_dist* dist, mrs_dist_info* info)
     if (dist->timing && dist->marks_valid) {
         MRS_HIP_TRY(hipEventSynchronize(dist->marks[4]));
         for (int i = 0; i < 4; ++i) MRS_HIP_TRY(hipEventElapsedTime(&info->last_ms[i], dist->marks[i], dist->marks[i + 1]));
+        float ms[kMaxPasses * 4 + 8];
+        char labels[(kMaxPasses * 4 + 8) * 32];
+        int count = 0;
+        if (int rc = mrs_plan_get_timings(dist->sort_plan, kMaxPasses * 4 + 8, ms, labels, &count)) return rc;
+        float sum = 0.f;
+        uint32_t passes = 0;
+        for (int i = 0; i < count; ++i)
+            if (std::strcmp(labels + 32 * i, "onesweep_pass") == 0) {
+                sum += ms[i];
+                ++passes;
+            }
+        info->last_sort_passes = passes;
+        info->last_sort_pass_ms = passes ? sum / passes : 0.f;
     }
     return MRS_OK;
 }

@@ -133,6 +133,8 @@ class DistributedSorter:
             "dist_recv_pairs_rank0": int(i.last_n_out),
             "dist_splitter_levels": int(i.last_levels),
             "dist_exact_cuts": int(i.last_exact_cuts),
+            "dist_local_sort_pass_ms": float(i.last_sort_pass_ms),
+            "dist_local_sort_passes": int(i.last_sort_passes),
         }
 
 
