@@ -16,6 +16,50 @@ pub const MORTON_UNIFORMS_BYTES: usize = 51248;
 pub struct mrs_context { _private: [u8; 0] }
 #[repr(C)]
 pub struct mrs_plan { _private: [u8; 0] }
+#[repr(C)]
+pub struct mrs_comm { _private: [u8; 0] }
+#[repr(C)]
+pub struct mrs_dist { _private: [u8; 0] }
+#[repr(C)]
+pub struct mrs_splitter { _private: [u8; 0] }
+
+/// `mrs_dist_desc`: the sharded sort of one rank.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct mrs_dist_desc {
+    pub n_local_max: u64,
+    pub key_words: i32,
+    pub payload_bytes: i32,
+    pub end_bit: i32,
+    pub reserved: i32,
+    pub tolerance: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct mrs_dist_info {
+    pub recv_capacity: u64,
+    pub device_bytes: u64,
+    pub last_levels: u32,
+    pub last_exact_cuts: u32,
+    pub last_n_out: u64,
+    pub last_ms: [f32; 4],
+    pub last_sort_pass_ms: f32,
+    pub last_sort_passes: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct mrs_split_result {
+    pub world: i32,
+    pub levels: i32,
+    pub total: u64,
+    pub rank_size: [u64; 16],
+    pub cut_key: [u64; 15],
+    pub exact_mask: u32,
+    pub reserved: u32,
+    pub send_count: [[u64; 16]; 16],
+}
 
 /// Replaces the constants of `src/constants.rs` and the sizing of `create_all_buffers`.
 #[repr(C)]
@@ -89,6 +133,27 @@ extern "C" {
                          keys_out: *mut c_void, vals_out: *mut c_void, shift: u32, bits: u32,
                          map_dev: *const u8, num_parts: u32, part_counts_dev: *mut u32,
                          stream: *mut c_void) -> c_int;
+    // ---- the sort sharded over the GPUs of a node (one rank per GPU, RCCL underneath) ----
+    pub fn mrs_comm_get_unique_id(id_out: *mut c_void) -> c_int; // 128 bytes, rank 0
+    pub fn mrs_comm_create_rccl(unique_id: *const c_void, rank: i32, world: i32, out: *mut *mut mrs_comm) -> c_int;
+    pub fn mrs_comm_wrap_rccl(nccl_comm: *mut c_void, rank: i32, world: i32, out: *mut *mut mrs_comm) -> c_int;
+    pub fn mrs_comm_create_local(world: i32, out: *mut *mut mrs_comm) -> c_int; // out[0..world)
+    pub fn mrs_comm_destroy(comm: *mut mrs_comm) -> c_int;
+    pub fn mrs_dist_create(ctx: *mut mrs_context, comm: *mut mrs_comm, desc: *const mrs_dist_desc,
+                           out: *mut *mut mrs_dist) -> c_int;
+    pub fn mrs_dist_destroy(dist: *mut mrs_dist) -> c_int;
+    pub fn mrs_dist_set_timing(dist: *mut mrs_dist, enable: c_int) -> c_int;
+    pub fn mrs_dist_get_info(dist: *mut mrs_dist, info: *mut mrs_dist_info) -> c_int;
+    pub fn mrs_dist_sort_pairs(dist: *mut mrs_dist, n_local: u64, keys_in: *const c_void, vals_in: *const c_void,
+                               keys_out: *mut *mut c_void, vals_out: *mut *mut c_void, n_out: *mut u64,
+                               stream: *mut c_void) -> c_int;
+    pub fn mrs_dist_check(dist: *mut mrs_dist, stream: *mut c_void) -> c_int;
+    pub fn mrs_splitter_create(world: i32, key_bits: i32, tolerance: u64, out: *mut *mut mrs_splitter) -> c_int;
+    pub fn mrs_splitter_destroy(sp: *mut mrs_splitter) -> c_int;
+    pub fn mrs_splitter_next(sp: *mut mrs_splitter, shift: *mut u32, bits: *mut u32, num_prefixes: *mut u32,
+                             prefixes: *mut u64) -> c_int;
+    pub fn mrs_splitter_feed(sp: *mut mrs_splitter, counts: *const u64) -> c_int;
+    pub fn mrs_splitter_get(sp: *const mrs_splitter, out: *mut mrs_split_result) -> c_int;
     pub fn mrs_generate_points(ctx: *mut mrs_context, seed: u64, n: u64, xyz_dev: *mut f32,
                                stream: *mut c_void) -> c_int;
     pub fn mrs_generate_u32(ctx: *mut mrs_context, seed: u64, stream_id: u64, n: u64, out_dev: *mut u32,

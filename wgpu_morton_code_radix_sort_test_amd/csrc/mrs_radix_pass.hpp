@@ -216,13 +216,46 @@ __device__ __forceinline__ uint32_t window_reduce(const StatusT (&v)[J], uint32_
 
 // base[index] = v.  With OFF32 the byte offset is known to fit 32 bits, which lets the
 // store take a scalar base and a 32-bit register offset instead of a 64-bit address.
+// Cache policy of the scatter's stores and of the tile loads in diagnostic builds
+// (-DMRS_STORE_POLICY=1: non-temporal stores, 2: write-through (sc1) stores of 4-byte elements;
+// -DMRS_LOAD_NT: non-temporal loads).  The product uses the default policy for both.
+#ifndef MRS_STORE_POLICY
+#define MRS_STORE_POLICY 0
+#endif
+template <typename T>
+__device__ __forceinline__ void policy_store(T* p, const T& v)
+{
+#if MRS_STORE_POLICY == 1
+    if constexpr (sizeof(T) <= 8) __builtin_nontemporal_store(v, p);
+    else *p = v;
+#elif MRS_STORE_POLICY == 2
+    if constexpr (sizeof(T) == 4)
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(p), *reinterpret_cast<const uint32_t*>(&v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+#else
+    *p = v;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ T policy_load(const T* p)
+{
+#ifdef MRS_LOAD_NT
+    if constexpr (sizeof(T) <= 8) return __builtin_nontemporal_load(p);
+    else return *p;
+#else
+    return *p;
+#endif
+}
+
 template <bool OFF32, typename T>
 __device__ __forceinline__ void store_element(T* base, uint32_t index, const T& v)
 {
     if constexpr (OFF32)
-        *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + index * static_cast<uint32_t>(sizeof(T))) = v;
+        policy_store(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + index * static_cast<uint32_t>(sizeof(T))), v);
     else
-        base[index] = v;
+        policy_store(base + index, v);
 }
 
 // Tile-local positions are below 2^16 (no tile shape exceeds 65536 elements), so two
@@ -319,7 +352,7 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     KeyT key[KPT];
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-        if (FULL || my_first + i * 64 < tile_valid) key[i] = keys_in[i * 64];
+        if (FULL || my_first + i * 64 < tile_valid) key[i] = policy_load(keys_in + i * 64);
         else key[i] = static_cast<KeyT>(~static_cast<KeyT>(0));
     }
 #ifdef MRS_STAMPS
@@ -511,7 +544,7 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
             const ValT* __restrict__ vals_in = static_cast<const ValT*>(a.vals_in) + tile_base + my_first;
 #pragma unroll
             for (int i = 0; i < KPT; ++i)
-                if (FULL || my_first + i * 64 < tile_valid) val[i] = vals_in[i * 64];
+                if (FULL || my_first + i * 64 < tile_valid) val[i] = policy_load(vals_in + i * 64);
         }
     }
 
