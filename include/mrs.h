@@ -239,7 +239,18 @@ int mrs_sort_pairs_noalloc(mrs_context* ctx, uint64_t n, uint32_t* keys_a, uint3
  * index_a filled with 0..n-1 first (index_a, index_b: u32[n] scratch), then
  * records_out[j] = records_in[index[j]] for records of record_bytes (a positive multiple of 4).
  * Keys end in keys_a or keys_b as reported by result_in_b; records_out must not alias records_in.
- * The sorted source indices stay in index_a or index_b (same side as the keys). */
+ * The sorted source indices stay in index_a or index_b (same side as the keys).
+ *
+ * This is also the layout a BVH builder reads (the consumer the reference's TriangleIndices
+ * anticipates with its commented-out `node_index`, src/types.rs:33,
+ * src/shaders/radix_sort_index.wgsl:11-17).  With S the side result_in_b names, for leaf i in [0, n):
+ *   keys_S[i]      the i-th smallest code, equal codes in source order (the sort is stable);
+ *   index_S[i]     the source position of that element: the leaf -> primitive map;
+ *   records_out[i] its record (e.g. the triangle's vertex indices), so leaf i needs no indirection.
+ * A Karras-style builder derives the tree from keys_S alone: delta(i, j) = clz(keys_S[i] ^ keys_S[j]),
+ * and for equal codes KEYBITS + clz(i ^ j), which is well defined because leaf numbers are unique and
+ * stability makes the order of equal codes reproducible.  Internal-node arrays (n - 1 nodes) are the
+ * builder's own; nothing here allocates them. */
 int mrs_sort_gather(mrs_plan* plan, uint64_t n, void* keys_a, void* keys_b, uint32_t* index_a,
                     uint32_t* index_b, const void* records_in, void* records_out,
                     uint32_t record_bytes, void* stream, int* result_in_b);

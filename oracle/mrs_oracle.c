@@ -367,7 +367,7 @@ static int translate_coords_lut(int i, int byte, int first_or_last)
 }
 
 /* morton_code.wgsl:103-127 (one item of the unrolled entry point) */
-void orc_morton_encode_lut(const void* blob_v, const void* vertices_v,
+void orc_morton_encode_lut(const void* blob_v, const void* vertices_v, uint64_t num_vertices,
                            const void* triangles_v, uint64_t n, uint32_t* codes)
 {
     const unsigned char* blob = (const unsigned char*)blob_v;
@@ -386,8 +386,11 @@ void orc_morton_encode_lut(const void* blob_v, const void* vertices_v,
         for (int c = 0; c < 3; ++c) {
             float v[3];
             for (int k = 0; k < 3; ++k) {
-                uint32_t vi = rd_u32(tris + t * 16 + 4 * k);
-                v[k] = rd_f32(verts + (uint64_t)vi * 48 + 4 * c);
+                /* a vertex index past the buffer is out of bounds in the shader (wgpu's robust
+                 * buffer access leaves the result implementation-defined): clamp to the last vertex */
+                uint64_t vi = rd_u32(tris + t * 16 + 4 * k);
+                if (vi >= num_vertices) vi = num_vertices - 1;
+                v[k] = rd_f32(verts + vi * 48 + 4 * c);
             }
             mn[c] = fminf(fminf(v[0], v[1]), v[2]);
             mx[c] = fmaxf(fmaxf(v[0], v[1]), v[2]);

@@ -102,8 +102,9 @@ uint64_t orc_count_unsorted(const uint32_t* keys, uint64_t n, int key_words,
 #define ORC_MORTON_LUT_WORDS 4608
 #define ORC_MORTON_SIZE_LUT_WORDS 8192
 /* Extended Morton code per triangle (morton_code.wgsl:103-127).  vertices:
- * stride 48 B, position at byte 0; triangles: stride 16 B; codes: u32[2n]. */
-void orc_morton_encode_lut(const void* blob, const void* vertices,
+ * stride 48 B, position at byte 0; triangles: stride 16 B; codes: u32[2n].
+ * Vertex indices >= num_vertices read the last vertex. */
+void orc_morton_encode_lut(const void* blob, const void* vertices, uint64_t num_vertices,
                            const void* triangles, uint64_t n, uint32_t* codes);
 /* 30-bit point Morton code; payload = original index.  No counterpart in the
  * reference (the metric's key shape). */

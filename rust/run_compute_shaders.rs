@@ -57,3 +57,55 @@ pub fn run_headless() -> mrs::Result<()> {
     if times_unsorted != 0 { log::error!("Not sorted!!! {}", times_unsorted); } else { println!("Sorted !!!"); }
     Ok(())
 }
+
+/// What `State` (src/state.rs:14-22) keeps across frames once the compute path is libmrs: the
+/// context, one stream, the buffer set and the plan.  `State::new` (src/state.rs:24-87) creates
+/// them once; `State::render` (src/state.rs:109-148) then re-uses them, where the reference calls
+/// `run_compute_shaders` and with it re-creates every buffer, pipeline and bind group per frame.
+pub struct ComputeState {
+    pub ctx: mrs::Context,
+    pub stream: hip::Stream,
+    pub buffers: Buffers,
+    host_uniforms: Vec<u8>,   // this frame's uploads, alive while the stream reads them
+    host_vertices: Vec<u8>,
+    host_triangles: Vec<u8>,
+}
+
+impl ComputeState {
+    pub fn new() -> mrs::Result<Self> {
+        let ctx = mrs::Context::new(0)?;
+        let stream = hip::Stream::new();
+        let n = NUM_TRIANGLES as u64;
+        let plan = mrs::Plan::new(&ctx, mrs::PlanDesc {
+            n, key_words: 2, payload_bytes: 16, digit_bits: BITS_PER_PASS as i32, begin_bit: 0,
+            end_bit: (BITS_PER_PASS * NUM_PASSES) as i32, algo: mrs::ALGO_ONESWEEP, tile_items: 0,
+        })?;
+        let buffers = Buffers {
+            vertices: hip::alloc(48 * NUM_VERTICES as usize), indices: hip::alloc(16 * n as usize),
+            indices_2: hip::alloc(16 * n as usize), morton_uniforms: hip::alloc(mrs::MORTON_UNIFORMS_BYTES),
+            morton_codes: hip::alloc(8 * n as usize), morton_codes_2: hip::alloc(8 * n as usize),
+            plan, result_in_2: false,
+        };
+        Ok(Self { ctx, stream, buffers, host_uniforms: vec![], host_vertices: vec![], host_triangles: vec![] })
+    }
+
+    /// The compute part of `State::render`: no allocation, no plan creation, no host synchronisation
+    /// beyond waiting for the previous frame's uploads to have left the host arrays.
+    pub fn render(&mut self) -> mrs::Result<()> {
+        self.stream.synchronize();
+        let (vertices, triangles, generator, _v, _t) = create_scene();
+        self.host_uniforms = encase_bytes(&create_morton_uniforms(&generator));
+        self.host_vertices = encase_bytes(&vertices);
+        self.host_triangles = encase_bytes(&triangles);
+        let b = &mut self.buffers;
+        hip::upload_async(&b.morton_uniforms, &self.host_uniforms, &self.stream);
+        hip::upload_async(&b.vertices, &self.host_vertices, &self.stream);
+        hip::upload_async(&b.indices, &self.host_triangles, &self.stream);
+        let n = NUM_TRIANGLES as u64;
+        self.ctx.morton_encode_lut(b.morton_uniforms.ptr(), b.vertices.ptr(), NUM_VERTICES as u64, b.indices.ptr(), n,
+                                   b.morton_codes.ptr() as *mut u32, self.stream.raw())?;
+        b.result_in_2 = b.plan.sort_pairs(n, b.morton_codes.ptr(), b.indices.ptr(), b.morton_codes_2.ptr(),
+                                          b.indices_2.ptr(), self.stream.raw())?;
+        Ok(())
+    }
+}

@@ -69,7 +69,7 @@ class Oracle:
         L.orc_count_unsorted.restype = _u64
         L.orc_count_unsorted.argtypes = [_u32p, _u64, _int, _u32]
         L.orc_morton_encode_lut.restype = None
-        L.orc_morton_encode_lut.argtypes = [_u8p, _u8p, _u8p, _u64, _u32p]
+        L.orc_morton_encode_lut.argtypes = [_u8p, _u8p, _u64, _u8p, _u64, _u32p]
         L.orc_morton_encode30.restype = None
         L.orc_morton_encode30.argtypes = [_f32p, _u64, _f32p, _f32p, _u32p, _u32p]
         L.orc_rand_u32.restype = _u32
@@ -120,7 +120,7 @@ class Oracle:
     def morton_encode_lut(self, blob, vertices, triangles):
         n = triangles.size // 16
         codes = np.empty(2 * n, dtype=np.uint32)
-        self.L.orc_morton_encode_lut(blob, vertices, triangles, n, codes)
+        self.L.orc_morton_encode_lut(blob, vertices, vertices.size // 48, triangles, n, codes)
         return codes
 
     def block_histogram(self, keys, n, key_words, shift, bits, tile):

@@ -59,6 +59,24 @@ def test_morton_encode_lut_matches_oracle(ctx, oracle, mrs, nv, nt):
         assert np.array_equal(to_u32(codes), oracle.morton_encode_lut(blob, verts, tris))
 
 
+def test_morton_encode_lut_out_of_range_vertex_index(ctx, oracle, mrs):
+    """A triangle that names a vertex past the end of the vertex buffer (undefined in the reference,
+    whose wgpu robustness layer decides): library and checker both read the last vertex."""
+    positions, indices, gen = mrs.scene.create_scene(100, 500, 3)
+    indices = indices.copy()
+    indices[7, 1] = 100          # first index past the buffer
+    indices[11, 2] = 0xFFFFFFFF  # and the largest one
+    verts = mrs.scene.pack_vertices(positions)
+    tris = mrs.scene.pack_triangles(indices)
+    blob = mrs.scene.create_morton_uniforms(gen)
+    codes = ctx.morton_encode_lut(to_dev(blob, ctx.device), to_dev(verts, ctx.device), to_dev(tris, ctx.device))
+    want = oracle.morton_encode_lut(blob, verts, tris)
+    assert np.array_equal(to_u32(codes), want)
+    clamped = indices.copy()
+    clamped[clamped >= 100] = 99
+    assert np.array_equal(want, oracle.morton_encode_lut(blob, verts, mrs.scene.pack_triangles(clamped)))
+
+
 # ---- single stages of the three-kernel pass ------------------------------------------
 @pytest.mark.parametrize("tile", [256, 1024, 8192])
 @pytest.mark.parametrize("bits", [4, 8])
@@ -313,6 +331,92 @@ def test_sort_gather_matches_oracle(ctx, oracle, mrs, key_words, record_words):
         src = to_u32(index)[:n].astype(np.int64)
         assert np.array_equal(recs.reshape(n, record_words)[src].reshape(-1), rv)
         plan.close()
+
+
+def _karras_tree(codes, key_bits):
+    """Binary radix tree over sorted codes (Karras 2012: determineRange + findSplit), with the
+    leaf number breaking ties between equal codes.  Returns (left, right, first, last) per internal
+    node; children >= n - 1 are leaves (leaf i is n - 1 + i)."""
+    n = len(codes)
+
+    def delta(i, j):
+        if j < 0 or j >= n:
+            return -1
+        x = int(codes[i]) ^ int(codes[j])
+        if x:
+            return key_bits - x.bit_length()
+        return key_bits + (32 - (i ^ j).bit_length())
+
+    left, right = [0] * (n - 1), [0] * (n - 1)
+    first, last = [0] * (n - 1), [0] * (n - 1)
+    for i in range(n - 1):
+        d = 1 if delta(i, i + 1) > delta(i, i - 1) else -1
+        dmin = delta(i, i - d)
+        lmax = 2
+        while delta(i, i + lmax * d) > dmin:
+            lmax *= 2
+        length, t = 0, lmax // 2
+        while t >= 1:
+            if delta(i, i + (length + t) * d) > dmin:
+                length += t
+            t //= 2
+        j = i + length * d
+        dnode = delta(i, j)
+        s, t = 0, length
+        while t > 1:
+            t = (t + 1) // 2
+            if delta(i, i + (s + t) * d) > dnode:
+                s += t
+        gamma = i + s * d + min(d, 0)
+        lo, hi = min(i, j), max(i, j)
+        left[i] = (n - 1 + gamma) if lo == gamma else gamma
+        right[i] = (n - 1 + gamma + 1) if hi == gamma + 1 else gamma + 1
+        first[i], last[i] = lo, hi
+    return left, right, first, last
+
+
+@pytest.mark.parametrize("code_mask", [0xFFFFFFFFFFFFFFFF, 0x0000000000FF0000])
+def test_sort_gather_output_feeds_a_bvh_builder(ctx, oracle, mrs, code_mask):
+    """The BVH-facing output (sorted codes, leaf -> primitive map, records in leaf order): a
+    Karras-style radix tree built from it on the host is a proper binary tree whose node ranges
+    nest, also when most codes are equal (the second mask leaves 256 distinct codes)."""
+    n = 3000
+    positions, indices, gen = mrs.scene.create_scene(1000, n, 7)
+    verts, tris = mrs.scene.pack_vertices(positions), mrs.scene.pack_triangles(indices)
+    codes = ctx.morton_encode_lut(to_dev(mrs.scene.create_morton_uniforms(gen), ctx.device), to_dev(verts, ctx.device),
+                                  to_dev(tris, ctx.device))
+    host_codes = (to_u32(codes).view(np.uint64) & np.uint64(code_mask))
+    ka = to_dev(host_codes.view(np.uint32), ctx.device)
+    kb = torch.empty_like(ka)
+    recs = to_dev(tris.view(np.uint32), ctx.device)
+    rout = torch.empty_like(recs)
+    plan = mrs.SortPlan(ctx, n, key_words=2, payload_bytes=4, digit_bits=8)
+    in_b, index = plan.sort_gather(ka, kb, recs, rout, 16)
+    plan.check()
+    sorted_codes = to_u32(kb if in_b else ka).view(np.uint64)
+    leaf_to_prim = to_u32(index)[:n].astype(np.int64)
+    # the three arrays agree with each other and with a stable sort
+    order = np.argsort(host_codes, kind="stable")
+    assert np.array_equal(sorted_codes, host_codes[order]) and np.array_equal(leaf_to_prim, order)
+    assert np.array_equal(to_u32(rout).reshape(n, 4), tris.view(np.uint32).reshape(n, 4)[leaf_to_prim])
+    left, right, first, last = _karras_tree(sorted_codes, 64)
+    # node 0 is the root and covers every leaf; children split their parent's range exactly; every
+    # leaf and every internal node other than the root has exactly one parent
+    assert (first[0], last[0]) == (0, n - 1)
+    seen = np.zeros(2 * n - 1, dtype=np.int64)
+    for i in range(n - 1):
+        for child, lo, hi in ((left[i], first[i], None), (right[i], None, last[i])):
+            seen[child] += 1
+            if child < n - 1:
+                if lo is not None:
+                    assert first[child] == lo and last[child] < last[i]
+                else:
+                    assert last[child] == hi and first[child] > first[i]
+        lmax = last[left[i]] if left[i] < n - 1 else left[i] - (n - 1)
+        rmin = first[right[i]] if right[i] < n - 1 else right[i] - (n - 1)
+        assert lmax + 1 == rmin
+    assert seen[0] == 0 and np.all(seen[1:] == 1)
+    plan.close()
 
 
 @pytest.mark.parametrize("bits,begin,end", [(8, 0, 32), (8, 0, 30), (4, 0, 30), (8, 3, 27)])
@@ -724,7 +828,8 @@ def test_errors_are_reported(ctx, mrs):
 
 
 @pytest.mark.parametrize("extra", [[], ["--gather"], ["--algo", "three_kernel"], ["--triangles", "70001", "--vertices", "5000", "--gather"],
-                                   ["--triangles", "70001", "--vertices", "5000", "--passes", "5"]])
+                                   ["--triangles", "70001", "--vertices", "5000", "--passes", "5"],
+                                   ["--frames", "6"], ["--frames", "3", "--gather", "--triangles", "70001", "--vertices", "5000"]])
 def test_cpp_host_driver(extra):
     """mrs_run, the compiled counterpart of run_headless (src/main.rs:690-1033): scene, encode,
     sort, read back, the reference's adjacent-pair check, and equality with std::stable_sort of the
@@ -738,4 +843,7 @@ def test_cpp_host_driver(extra):
     r = subprocess.run([exe] + extra, capture_output=True, text=True, timeout=100)
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["sorted"] and out["matches_stable_sort"] and not out["all_zero"]
+    assert out["sorted"] and out["matches_stable_sort"] and not out.get("all_zero", False)
+    if "--frames" in extra:
+        # the per-frame caller (State::render, src/state.rs:109-148) on buffers and a plan made once
+        assert out["frames"] == int(extra[extra.index("--frames") + 1]) and out["device_ms_per_frame"] > 0

@@ -9,7 +9,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wgpu_morton_code_radix_sort_test_amd as mrs  # noqa: E402
-from wgpu_morton_code_radix_sort_test_amd.dist import bucket_to_rank_map  # noqa: E402
+
+
+def bucket_to_part_table(counts, parts):
+    """u8 table: bucket b goes to the part its first element falls in when the total is cut evenly."""
+    c = np.asarray(counts, dtype=np.int64)
+    before = np.concatenate([[0], np.cumsum(c)[:-1]])
+    return np.minimum(parts - 1, before * parts // max(1, int(c.sum()))).astype(np.uint8)
 
 
 def main():
@@ -25,7 +31,7 @@ def main():
     ko, vo = torch.empty_like(keys), torch.empty_like(idx)
     for parts in (1, 2, 4, 8, 16):
         counts = ctx.bucket_histogram(keys, n, 1, 20, 12)
-        table = bucket_to_rank_map(counts.cpu().numpy(), parts)
+        table = bucket_to_part_table(counts.cpu().numpy(), parts)
         table_dev = torch.from_numpy(table).to(ctx.device)
         for what in ("bucket_histogram", "partition"):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <numeric>
 
@@ -144,30 +145,22 @@ void Buffers::release()
     *this = Buffers();
 }
 
-static int upload(const std::vector<uint8_t>& host, void** dev, hipStream_t s)
+// create_all_buffers, src/main.rs:31-85, plus the plan that owns the sort's temporaries: everything
+// a frame needs that does not change from frame to frame.
+int create_all_buffers(mrs_context* ctx, const Constants& c, Buffers* b)
 {
-    HOST_HIP_TRY(hipMalloc(dev, host.size()));
-    HOST_HIP_TRY(hipMemcpyAsync(*dev, host.data(), host.size(), hipMemcpyHostToDevice, s));
-    return MRS_OK;
-}
-
-int run_compute_shaders(mrs_context* ctx, void* stream, const Constants& c, Buffers* b)
-{
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const Scene scene = create_scene(c);
-    const MortonCodeGenerator gen(scene.scene_min, scene.scene_max);
-    const std::vector<uint8_t> uniforms = create_morton_uniforms(gen), verts = pack_vertices(scene),
-                               tris = pack_triangles(scene);
     const uint64_t n = c.num_triangles;
     b->num_triangles = c.num_triangles;
-    // create_all_buffers, src/main.rs:31-85
-    if (int rc = upload(uniforms, &b->morton_uniforms, s)) return rc;
-    if (int rc = upload(verts, &b->vertices, s)) return rc;
-    if (int rc = upload(tris, &b->indices, s)) return rc;
-    HOST_HIP_TRY(hipStreamSynchronize(s));  // the host vectors die at return
-    HOST_HIP_TRY(hipMalloc(&b->indices_2, tris.size()));
+    HOST_HIP_TRY(hipMalloc(&b->morton_uniforms, MRS_MORTON_UNIFORMS_BYTES));
+    HOST_HIP_TRY(hipMalloc(&b->vertices, static_cast<size_t>(c.num_vertices) * MRS_VERTEX_STRIDE));
+    HOST_HIP_TRY(hipMalloc(&b->indices, n * MRS_TRIANGLE_STRIDE));
+    HOST_HIP_TRY(hipMalloc(&b->indices_2, n * MRS_TRIANGLE_STRIDE));
     HOST_HIP_TRY(hipMalloc(&b->morton_codes, n * 8));
     HOST_HIP_TRY(hipMalloc(&b->morton_codes_2, n * 8));
+    if (c.gather_payload) {
+        HOST_HIP_TRY(hipMalloc(&b->source_index, n * 4));
+        HOST_HIP_TRY(hipMalloc(&b->source_index_2, n * 4));
+    }
     mrs_plan_desc d{};
     d.n = n;
     d.key_words = 2;
@@ -177,14 +170,25 @@ int run_compute_shaders(mrs_context* ctx, void* stream, const Constants& c, Buff
     d.end_bit = static_cast<int32_t>(c.bits_per_pass * c.num_passes);
     d.algo = c.algo;
     d.tile_items = c.tile_items;
-    if (int rc = mrs_plan_create(ctx, &d, &b->plan)) return rc;
+    return mrs_plan_create(ctx, &d, &b->plan);
+}
+
+// Uploads one frame's scene into existing buffers and enqueues "Morton Coding" and the pass loop
+// (src/main.rs:581-665).  No allocation; the host arrays must stay alive until the stream has
+// consumed them (the callers below keep or synchronise them).
+int record_frame(mrs_context* ctx, void* stream, const Constants& c, const std::vector<uint8_t>& uniforms,
+                 const std::vector<uint8_t>& verts, const std::vector<uint8_t>& tris, Buffers* b)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t n = c.num_triangles;
+    HOST_HIP_TRY(hipMemcpyAsync(b->morton_uniforms, uniforms.data(), uniforms.size(), hipMemcpyHostToDevice, s));
+    HOST_HIP_TRY(hipMemcpyAsync(b->vertices, verts.data(), verts.size(), hipMemcpyHostToDevice, s));
+    HOST_HIP_TRY(hipMemcpyAsync(b->indices, tris.data(), tris.size(), hipMemcpyHostToDevice, s));
     // "Morton Coding", src/main.rs:581-592
     if (int rc = mrs_morton_encode_lut(ctx, b->morton_uniforms, b->vertices, c.num_vertices, b->indices, n,
                                        static_cast<uint32_t*>(b->morton_codes), stream))
         return rc;
     if (c.gather_payload) {
-        HOST_HIP_TRY(hipMalloc(&b->source_index, n * 4));
-        HOST_HIP_TRY(hipMalloc(&b->source_index_2, n * 4));
         b->triangles_in_2 = true;
         return mrs_sort_gather(b->plan, n, b->morton_codes, b->morton_codes_2, static_cast<uint32_t*>(b->source_index),
                                static_cast<uint32_t*>(b->source_index_2), b->indices, b->indices_2,
@@ -197,35 +201,76 @@ int run_compute_shaders(mrs_context* ctx, void* stream, const Constants& c, Buff
     return rc;
 }
 
+// The reference's entry point as it stands: every call builds the scene, creates every buffer and
+// records the passes (src/main.rs:376-688).
+int run_compute_shaders(mrs_context* ctx, void* stream, const Constants& c, Buffers* b)
+{
+    const Scene scene = create_scene(c);
+    const MortonCodeGenerator gen(scene.scene_min, scene.scene_max);
+    const std::vector<uint8_t> uniforms = create_morton_uniforms(gen), verts = pack_vertices(scene),
+                               tris = pack_triangles(scene);
+    if (int rc = create_all_buffers(ctx, c, b)) return rc;
+    if (int rc = record_frame(ctx, stream, c, uniforms, verts, tris, b)) return rc;
+    HOST_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));  // the host vectors die at return
+    return MRS_OK;
+}
+
+// ---- State: what the reference keeps across frames (src/state.rs:14-22), with the buffers and
+// the plan added to it so that render() allocates nothing ---------------------------------------
+int State::init(const Constants& constants)
+{
+    c = constants;
+    int dev = 0;
+    HOST_HIP_TRY(hipGetDevice(&dev));
+    if (int rc = mrs_context_create(dev, &ctx)) return rc;  // State::new, src/state.rs:24-87
+    HOST_HIP_TRY(hipStreamCreate(reinterpret_cast<hipStream_t*>(&stream)));
+    return create_all_buffers(ctx, c, &buffers);
+}
+
+// State::render, src/state.rs:109-148: one frame = scene (here: the same seed-7 scene with the
+// frame number folded into the seed, so that consecutive frames differ), encode, sort.  The
+// reference re-creates buffers, pipelines and bind groups here on every frame; this one re-uses
+// what init() made: no hipMalloc, no plan creation, no host synchronisation.
+int State::render()
+{
+    Constants frame = c;
+    frame.rng_seed = c.rng_seed + frames;
+    // the previous frame's uploads must have left the host arrays before they are rewritten
+    HOST_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    const Scene scene = create_scene(frame);
+    const MortonCodeGenerator gen(scene.scene_min, scene.scene_max);
+    uniforms = create_morton_uniforms(gen);
+    verts = pack_vertices(scene);
+    tris = pack_triangles(scene);
+    ++frames;
+    return record_frame(ctx, stream, c, uniforms, verts, tris, &buffers);
+}
+
+void State::destroy()
+{
+    buffers.release();
+    if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream));
+    if (ctx) mrs_context_destroy(ctx);
+    ctx = nullptr;
+    stream = nullptr;
+}
+
 static uint64_t select_bits(uint64_t value, uint32_t i)  // src/main.rs:1042-1051
 {
     return i >= 8 ? value : value & ((1ull << (i * 8)) - 1ull);
 }
 
-int run_headless(const Constants& c, HeadlessResult* res, bool verbose)
+// Read-back and checks of one finished frame: the adjacent-pair check of src/main.rs:831-864 and,
+// beyond the reference, keys AND payload against a stable sort of a second encode of the same scene.
+static int check_frame(mrs_context* ctx, hipStream_t s, const Constants& c, const Buffers& b, HeadlessResult* res,
+                       bool verbose)
 {
-    mrs_context* ctx = nullptr;
-    int dev = 0;
-    HOST_HIP_TRY(hipGetDevice(&dev));
-    if (int rc = mrs_context_create(dev, &ctx)) return rc;
-    hipStream_t s;
-    HOST_HIP_TRY(hipStreamCreate(&s));
-    Buffers b;
-    int rc = run_compute_shaders(ctx, s, c, &b);
-    if (rc == MRS_OK) rc = mrs_plan_check(b.plan, s);
-    if (rc != MRS_OK) {
-        std::fprintf(stderr, "mrs error %d: %s\n", rc, mrs_last_error_string());
-        b.release();
-        mrs_context_destroy(ctx);
-        return rc;
-    }
     const uint32_t n = c.num_triangles;
     std::vector<uint64_t> keys(n), keys_in(n);
     std::vector<uint32_t> tris(static_cast<size_t>(n) * 4);
     HOST_HIP_TRY(hipMemcpy(keys.data(), b.result_in_2 ? b.morton_codes_2 : b.morton_codes, n * 8ull, hipMemcpyDeviceToHost));
     HOST_HIP_TRY(hipMemcpy(tris.data(), b.triangles_in_2 ? b.indices_2 : b.indices, n * 16ull, hipMemcpyDeviceToHost));
 
-    // adjacent-pair check, src/main.rs:831-864
     res->sorted = true;
     res->all_zero = true;
     res->times_unsorted = 0;
@@ -234,18 +279,23 @@ int run_headless(const Constants& c, HeadlessResult* res, bool verbose)
         if (before > after) { res->times_unsorted++; res->sorted = false; }
         if (before != 0 || after != 0) res->all_zero = false;
     }
+    res->key_checksum = 0;
     for (uint64_t k : keys) res->key_checksum = res->key_checksum * 1099511628211ull + k;
 
-    // beyond the reference: keys and payload against a stable sort of a second encode
     Buffers b2;
-    rc = MRS_OK;
+    int rc = MRS_OK;
     {
         const Scene scene = create_scene(c);
-        const std::vector<uint8_t> t = pack_triangles(scene);
+        const MortonCodeGenerator gen(scene.scene_min, scene.scene_max);
+        const std::vector<uint8_t> t = pack_triangles(scene), v = pack_vertices(scene), u = create_morton_uniforms(gen);
         HOST_HIP_TRY(hipMalloc(&b2.morton_codes, n * 8ull));
         HOST_HIP_TRY(hipMalloc(&b2.indices, t.size()));
+        HOST_HIP_TRY(hipMalloc(&b2.vertices, v.size()));
+        HOST_HIP_TRY(hipMalloc(&b2.morton_uniforms, u.size()));
         HOST_HIP_TRY(hipMemcpy(b2.indices, t.data(), t.size(), hipMemcpyHostToDevice));
-        rc = mrs_morton_encode_lut(ctx, b.morton_uniforms, b.vertices, c.num_vertices, b2.indices, n,
+        HOST_HIP_TRY(hipMemcpy(b2.vertices, v.data(), v.size(), hipMemcpyHostToDevice));
+        HOST_HIP_TRY(hipMemcpy(b2.morton_uniforms, u.data(), u.size(), hipMemcpyHostToDevice));
+        rc = mrs_morton_encode_lut(ctx, b2.morton_uniforms, b2.vertices, c.num_vertices, b2.indices, n,
                                    static_cast<uint32_t*>(b2.morton_codes), s);
         HOST_HIP_TRY(hipStreamSynchronize(s));
         HOST_HIP_TRY(hipMemcpy(keys_in.data(), b2.morton_codes, n * 8ull, hipMemcpyDeviceToHost));
@@ -267,9 +317,65 @@ int run_headless(const Constants& c, HeadlessResult* res, bool verbose)
         if (res->all_zero) std::printf("all zero!!!\n");
     }
     b2.release();
+    return rc;
+}
+
+int run_headless(const Constants& c, HeadlessResult* res, bool verbose)
+{
+    mrs_context* ctx = nullptr;
+    int dev = 0;
+    HOST_HIP_TRY(hipGetDevice(&dev));
+    if (int rc = mrs_context_create(dev, &ctx)) return rc;
+    hipStream_t s;
+    HOST_HIP_TRY(hipStreamCreate(&s));
+    Buffers b;
+    int rc = run_compute_shaders(ctx, s, c, &b);
+    if (rc == MRS_OK) rc = mrs_plan_check(b.plan, s);
+    if (rc != MRS_OK) std::fprintf(stderr, "mrs error %d: %s\n", rc, mrs_last_error_string());
+    else rc = check_frame(ctx, s, c, b, res, verbose);
     b.release();
     (void)hipStreamDestroy(s);
     mrs_context_destroy(ctx);
+    return rc;
+}
+
+int run_frames(const Constants& c, uint32_t frames, HeadlessResult* res, double* ms_per_frame, double* device_ms_per_frame)
+{
+    State st;
+    int rc = st.init(c);
+    if (rc != MRS_OK) {
+        std::fprintf(stderr, "mrs error %d: %s\n", rc, mrs_last_error_string());
+        st.destroy();
+        return rc;
+    }
+    hipStream_t s = static_cast<hipStream_t>(st.stream);
+    hipEvent_t e0, e1;
+    HOST_HIP_TRY(hipEventCreate(&e0));
+    HOST_HIP_TRY(hipEventCreate(&e1));
+    double device_ms = 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t f = 0; f < frames && rc == MRS_OK; ++f) {
+        HOST_HIP_TRY(hipEventRecord(e0, s));
+        rc = st.render();
+        HOST_HIP_TRY(hipEventRecord(e1, s));
+        HOST_HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HOST_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        device_ms += ms;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (rc == MRS_OK) rc = mrs_plan_check(st.buffers.plan, s);
+    if (rc != MRS_OK) std::fprintf(stderr, "mrs error %d: %s\n", rc, mrs_last_error_string());
+    if (rc == MRS_OK) {
+        *ms_per_frame = std::chrono::duration<double, std::milli>(t1 - t0).count() / (frames ? frames : 1);
+        *device_ms_per_frame = device_ms / (frames ? frames : 1);
+        Constants last = c;
+        last.rng_seed = c.rng_seed + st.frames - 1;
+        rc = check_frame(st.ctx, s, last, st.buffers, res, false);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    st.destroy();
     return rc;
 }
 

@@ -80,6 +80,26 @@ struct Buffers {
 // (a hipStream_t).  Records only; returns an MRS_* status.
 int run_compute_shaders(mrs_context* ctx, void* stream, const Constants& c, Buffers* out);
 
+// The two halves of run_compute_shaders for hosts that keep their buffers across frames.
+int create_all_buffers(mrs_context* ctx, const Constants& c, Buffers* out);
+int record_frame(mrs_context* ctx, void* stream, const Constants& c, const std::vector<uint8_t>& uniforms,
+                 const std::vector<uint8_t>& verts, const std::vector<uint8_t>& tris, Buffers* b);
+
+// Counterpart of the reference's State (src/state.rs:14-22, 24-87, 109-148): init() once, render()
+// per frame.  Unlike the reference's render(), which calls run_compute_shaders and with it
+// re-creates every buffer, pipeline and bind group each frame, render() here allocates nothing.
+struct State {
+    mrs_context* ctx = nullptr;
+    void* stream = nullptr;  // hipStream_t
+    Constants c;
+    Buffers buffers;
+    std::vector<uint8_t> uniforms, verts, tris;  // this frame's uploads (alive while the stream reads them)
+    uint64_t frames = 0;
+    int init(const Constants& constants);
+    int render();
+    void destroy();
+};
+
 struct HeadlessResult {
     bool sorted = false;
     bool all_zero = true;
@@ -90,6 +110,10 @@ struct HeadlessResult {
 
 // run + synchronise + read back + the adjacent-pair check of src/main.rs:819-864.
 int run_headless(const Constants& c, HeadlessResult* res, bool verbose);
+// `frames` calls of State::render on one State, then the checks of run_headless on the last frame;
+// *ms_per_frame = wall time per frame (scene generation on the CPU included, as in the reference's loop),
+// *device_ms_per_frame = HIP-event time of the enqueued work per frame.
+int run_frames(const Constants& c, uint32_t frames, HeadlessResult* res, double* ms_per_frame, double* device_ms_per_frame);
 
 }  // namespace mrs_host
 #endif

@@ -622,8 +622,14 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
 // consecutive tiles, block g to die g % 8: a workgroup draws from the list of the die it runs
 // on (hardware register XCC_ID), and from the other lists once its own is exhausted.  Every
 // list is drawn in ascending order and there are exactly as many workgroups as tiles, so the
-// lowest unfinished tile is always held by a running workgroup or is the next to be drawn:
-// the look-back cannot starve, whatever the die id reads.
+// lowest unfinished tile is either held by a running workgroup or the next to be drawn ON ITS
+// DIE: the look-back makes progress as long as this kernel keeps getting workgroup slots on
+// every die, which holds when it has the device to itself or shares it with kernels that end on
+// their own (a single-list pass, a collective).  Two die-aware passes at once could each hold the
+// slots the other waits for; the host never launches that combination (begin_ticketed_call in
+// mrs_api.hip) and a wait that does starve ends in the time-out of the look-back, not in a hang.
+// With B = 0 there is one list: drawn tiles are always a prefix, the lowest unfinished tile is
+// always running, and one free slot anywhere is enough.
 __device__ __forceinline__ uint32_t draw_tile(const PassArgs& a)
 {
     const uint32_t B = a.xcd_block;
