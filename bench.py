@@ -194,7 +194,9 @@ def main():
 
         comm = Communicator.rccl(rank, world)
         # the keys are 30-bit Morton codes: all 4096 buckets of the top digit are live
-        sorter = DistributedSorter(ctx, comm, n, key_words=1, payload_words=1, end_bit=30)
+        # MRS_BENCH_DIST_CHUNKS: pieces a rank's share arrives in (0 = the library's choice; rehearsal aid)
+        chunks = int(os.environ.get("MRS_BENCH_DIST_CHUNKS", "0"))
+        sorter = DistributedSorter(ctx, comm, n, key_words=1, payload_words=1, end_bit=30, exchange_chunks=chunks)
         # every rank shares the scene bounds, so that the key ranges of the slices overlap fully
         inputs = []
         for j in range(pool):
@@ -404,7 +406,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"2^{args.log2n} (30-bit Morton key, u32 index) pairs per GPU from uniform random 3D points, "
-                            f"{args.digit_bits}-bit digits over all 32 key bits, {args.algo}",
+                            + (f"8-bit digits over key bits [0, 30), onesweep local sorts" if distributed else
+                               f"{args.digit_bits}-bit digits over all 32 key bits, {args.algo}"),
                 "pairs_per_gpu": n,
                 "total_pairs": total_pairs,
                 "digit_bits": args.digit_bits,

@@ -311,7 +311,10 @@ typedef struct mrs_dist_desc {
     int32_t key_words;      /* 1 or 2, as mrs_plan_desc                                            */
     int32_t payload_bytes;  /* 0 or 4                                                              */
     int32_t end_bit;        /* keys are compared on bits [0, end_bit); higher bits must be zero    */
-    int32_t reserved;
+    int32_t exchange_chunks; /* pieces a rank's share arrives in: 1 = exchange, then sort; 2 = the
+                               share is cut in two consecutive key ranges and the sort of the first
+                               runs beside the exchange of the second (needs 2 * world <= 16);
+                               0 = chosen by the library (2 for 2..8 ranks)                         */
     uint64_t tolerance;     /* elements a cut may miss its ideal position by before the splitter
                                refines it; 0 = n_local_max / 256                                   */
 } mrs_dist_desc;
@@ -323,7 +326,8 @@ typedef struct mrs_dist_info {
     uint32_t last_exact_cuts; /* cuts of the last call placed inside a run of equal keys           */
     uint64_t last_n_out;
     float last_ms[4];         /* last call with timing on: histogram + collectives + splitter,
-                                 partition, exchange, local sort                                   */
+                                 partition, exchange (all pieces; with 2 pieces the sort of the
+                                 first overlaps it), local sort after the last piece arrived       */
     float last_sort_pass_ms;  /* last call with timing on: mean duration of one digit pass of the
                                  local sort (HIP events on the launch stream)                      */
     uint32_t last_sort_passes;

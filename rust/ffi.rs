@@ -31,7 +31,7 @@ pub struct mrs_dist_desc {
     pub key_words: i32,
     pub payload_bytes: i32,
     pub end_bit: i32,
-    pub reserved: i32,
+    pub exchange_chunks: i32,
     pub tolerance: u64,
 }
 

@@ -52,7 +52,7 @@ def rank_keys(oracle, n, key_words, dist, seed, end_bit):
     return k.reshape(-1)
 
 
-def run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, tolerance, rounds=1):
+def run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, tolerance, rounds=1, chunks=0):
     """One thread per rank on GPU 0; returns per-rank (keys, payload) numpy arrays and infos."""
     from wgpu_morton_code_radix_sort_test_amd.dist import Communicator, DistributedSorter
 
@@ -70,7 +70,7 @@ def run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, tolerance, round
                 keys = to_dev(host_keys[r], ctx.device) if n else torch.zeros(key_words, dtype=torch.int32, device=ctx.device)
                 vals = (torch.arange(n, dtype=torch.int64, device=ctx.device) + int(offsets[r])).to(torch.int32)
                 sorter = DistributedSorter(ctx, comms[r], max(max(sizes), 1), key_words=key_words, payload_words=1,
-                                           end_bit=end_bit, tolerance=tolerance)
+                                           end_bit=end_bit, tolerance=tolerance, exchange_chunks=chunks)
                 for _ in range(rounds):
                     ok, ov = sorter.sort(keys, vals, n=n, stream=stream)
                 sorter.check(stream=stream)
@@ -113,25 +113,29 @@ def check_against_oracle(oracle, results, host_keys, sizes, key_words, end_bit, 
 
 
 CASES = [
-    # world, key_words, end_bit, distribution, tolerance (None = default)
-    (2, 1, 30, "morton30", None),
-    (3, 1, 32, "random", None),
-    (8, 1, 30, "morton30", None),
-    (8, 1, 32, "all_equal", None),
-    (4, 1, 30, "all_equal", 1),
-    (8, 1, 32, "hot_bucket", None),
-    (5, 1, 32, "few_values", None),
-    (4, 1, 32, "sorted", None),
-    (3, 1, 32, "random", 1),
-    (4, 2, 64, "random", None),
-    (4, 2, 64, "all_equal", None),
-    (3, 2, 50, "hot_bucket", None),
-    (16, 1, 32, "few_values", None),
+    # world, key_words, end_bit, distribution, tolerance (None = default), pieces per rank (0 = library's choice)
+    (2, 1, 30, "morton30", None, 0),
+    (2, 1, 30, "morton30", None, 1),
+    (3, 1, 32, "random", None, 0),
+    (8, 1, 30, "morton30", None, 0),
+    (8, 1, 32, "all_equal", None, 0),
+    (8, 1, 32, "all_equal", None, 1),
+    (4, 1, 30, "all_equal", 1, 2),
+    (8, 1, 32, "hot_bucket", None, 0),
+    (8, 1, 32, "hot_bucket", None, 1),
+    (5, 1, 32, "few_values", None, 0),
+    (4, 1, 32, "sorted", None, 2),
+    (3, 1, 32, "random", 1, 0),
+    (4, 2, 64, "random", None, 0),
+    (4, 2, 64, "all_equal", None, 0),
+    (3, 2, 50, "hot_bucket", None, 1),
+    (16, 1, 32, "few_values", None, 0),
+    (1, 1, 32, "random", None, 2),
 ]
 
 
-@pytest.mark.parametrize("world,key_words,end_bit,dist,tolerance", CASES)
-def test_local_ranks_match_one_stable_sort(oracle, mrs, world, key_words, end_bit, dist, tolerance):
+@pytest.mark.parametrize("world,key_words,end_bit,dist,tolerance,chunks", CASES)
+def test_local_ranks_match_one_stable_sort(oracle, mrs, world, key_words, end_bit, dist, tolerance, chunks):
     rng = np.random.default_rng(world * 7 + end_bit)
     sizes = [int(rng.integers(20000, 90000)) for _ in range(world)]
     if world >= 3:
@@ -140,11 +144,13 @@ def test_local_ranks_match_one_stable_sort(oracle, mrs, world, key_words, end_bi
     host_keys = [rank_keys(oracle, n, key_words, dist, seed=31 * r + 1, end_bit=end_bit) for r, n in enumerate(sizes)]
     # tolerance 0 in the C ABI selects the default (n_local_max / 256); 1 forces every cut down to the key
     tol = max(sizes) // 256 if tolerance is None else tolerance
-    results, infos = run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, 0 if tolerance is None else tolerance)
+    results, infos = run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, 0 if tolerance is None else tolerance,
+                               chunks=chunks)
     check_against_oracle(oracle, results, host_keys, sizes, key_words, end_bit, tol)
+    pieces = chunks or (2 if 2 <= world <= 8 else 1)
     if dist == "all_equal" and world > 1:
         # every cut falls inside the one run of equal keys: all levels, all cuts by element order
-        assert all(i.last_exact_cuts == world - 1 for i in infos)
+        assert all(i.last_exact_cuts == world * pieces - 1 for i in infos)
         total = sum(sizes)
         assert [r[1].size for r in results] == [total * (r + 1) // world - total * r // world for r in range(world)]
     if dist == "morton30" and tolerance is None and world <= 3:

@@ -42,15 +42,33 @@ def main():
     ap.add_argument("--fetch-dir", default="gpurun_out/pmc_fetch")
     ap.add_argument("--write-dir", default="gpurun_out/pmc_write")
     ap.add_argument("--log2n", type=int, default=28)
+    ap.add_argument("--root", default="", help="directory written by tools/collect_profiles.sh (gpurun_out/TAG): every "
+                                               "prof_NAME below it becomes profiles/TAG_NAME_kernel_stats.csv, and its "
+                                               "pmc_fetch / pmc_write feed traffic.json")
+    ap.add_argument("--measured", default="", help="free text stored in traffic.json (date, commit)")
     args = ap.parse_args()
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     n = 1 << args.log2n
 
-    for path in glob.glob(os.path.join(ROOT, args.stats_dir, "**", "*kernel_stats.csv"), recursive=True):
+    def library_rows(path):
         rows = list(csv.reader(open(path)))
-        keep = [rows[0]] + [r for r in rows[1:] if "mrs::" in r[0] or "rocclr" in r[0]]
-        with open(os.path.join(ROOT, "profiles", f"{args.tag}_kernel_stats.csv"), "w", newline="") as f:
-            csv.writer(f).writerows(keep)
+        # library kernels, RCCL's and the runtime's copy/fill kernels
+        return [rows[0]] + [r for r in rows[1:] if "mrs::" in r[0] or "rocclr" in r[0] or "nccl" in r[0].lower()]
+
+    if args.root:
+        for d in sorted(glob.glob(os.path.join(ROOT, args.root, "prof_*"))):
+            if not os.path.isdir(d):
+                continue
+            name = os.path.basename(d)[len("prof_"):]
+            for path in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+                with open(os.path.join(ROOT, "profiles", f"{args.tag}_{name}_kernel_stats.csv"), "w", newline="") as f:
+                    csv.writer(f).writerows(library_rows(path))
+        args.fetch_dir = os.path.join(args.root, "pmc_fetch")
+        args.write_dir = os.path.join(args.root, "pmc_write")
+    else:
+        for path in glob.glob(os.path.join(ROOT, args.stats_dir, "**", "*kernel_stats.csv"), recursive=True):
+            with open(os.path.join(ROOT, "profiles", f"{args.tag}_kernel_stats.csv"), "w", newline="") as f:
+                csv.writer(f).writerows(library_rows(path))
 
     fetch = counter_means(os.path.join(ROOT, args.fetch_dir, "**", "*counter_collection.csv"), "FETCH_SIZE")
     write = counter_means(os.path.join(ROOT, args.write_dir, "**", "*counter_collection.csv"), "WRITE_SIZE")
@@ -77,6 +95,7 @@ def main():
                                   "applied": factor},
             "write_calibration": {"morton_encode30 (8 B/point)": cal_w},
             "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs of tools/sort_once.py",
+            "measured": args.measured,
         }
         with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
             json.dump(out, f, indent=1)

@@ -57,7 +57,7 @@ class DistDesc(ctypes.Structure):
         ("key_words", ctypes.c_int32),
         ("payload_bytes", ctypes.c_int32),
         ("end_bit", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("exchange_chunks", ctypes.c_int32),
         ("tolerance", ctypes.c_uint64),
     ]
 

@@ -85,10 +85,16 @@ bool config_supported(unsigned long long n, int key_words, int payload_bytes, in
         int t = 0, k = 0;
         if (std::sscanf(e, "%d,%d", &t, &k) == 2 && tile_items == 0) c = {t, k};
     }
-    // what the kernel table holds (mrs_radix_dispatch.hpp)
-    const int tile = c.threads * c.kpt;
-    if (payload_bytes == 16 && tile > 8192) return false;
-    if (payload_bytes != 16 && !small_pairs && tile > 4096 && !(c.threads == 1024 && c.kpt == 16)) return false;
+    // what the kernel table holds (mrs_radix_dispatch.hpp): three shapes for every element type,
+    // 1024 x 8 for 16-byte payloads, 1024 x 16 for payloads of at most 4 bytes, and the large
+    // shapes for 32-bit keys with such payloads.  Anything else (the override above can name any
+    // pair) is refused here, at plan creation, not at the first launch.
+    auto is = [&](int t, int k) { return c.threads == t && c.kpt == k; };
+    bool known = is(256, 1) || is(256, 4) || is(512, 8);
+    if (payload_bytes == 16) known = known || is(1024, 8);
+    if (payload_bytes <= 4) known = known || is(1024, 16);
+    if (small_pairs) known = known || is(512, 16) || is(512, 32) || is(1024, 32);
+    if (!known) return false;
     if (cfg) *cfg = c;
     return true;
 }
@@ -120,6 +126,9 @@ struct DeviceActivity {
     std::mutex m;
     hipEvent_t event = nullptr;  // created by mrs_context_create with the device current
     hipStream_t stream = nullptr;
+    // Calls of one lineage (the plans of one sharded-sort handle) are ordered among themselves by
+    // events even where they use two streams, and count as one stream here.
+    const void* lineage = nullptr;
     bool recorded = false;
 };
 static DeviceActivity g_activity[kMaxDevices];
@@ -168,13 +177,14 @@ static uint32_t xcd_block_tiles(const mrs_context* ctx)
 // a die-aware call on another stream of this device may still be running (DeviceActivity).
 // Under stream capture nothing can be queried: the captured work keeps the context's setting,
 // and replays that overlap on one device are the caller's to avoid.
-static uint32_t begin_ticketed_call(const mrs_context* ctx, hipStream_t s)
+static uint32_t begin_ticketed_call(const mrs_context* ctx, hipStream_t s, const void* lineage)
 {
     uint32_t block = xcd_block_tiles(ctx);
     if (block == 0 || stream_is_capturing(s)) return block;
     DeviceActivity& a = g_activity[ctx->device];
     std::lock_guard<std::mutex> lock(a.m);
-    if (a.recorded && a.stream != s && a.event) {
+    const bool same_order = a.stream == s || (lineage && lineage == a.lineage);
+    if (a.recorded && !same_order && a.event) {
         if (hipEventQuery(a.event) != hipSuccess) block = 0;
         (void)hipGetLastError();  // "not ready" is an answer, not an error to report later
     }
@@ -182,7 +192,7 @@ static uint32_t begin_ticketed_call(const mrs_context* ctx, hipStream_t s)
 }
 
 // Leaves the mark the next call looks for.  Only calls that did use die-aware tickets need one.
-static void end_ticketed_call(const mrs_context* ctx, hipStream_t s, uint32_t block)
+static void end_ticketed_call(const mrs_context* ctx, hipStream_t s, uint32_t block, const void* lineage)
 {
     if (block == 0 || stream_is_capturing(s)) return;
     DeviceActivity& a = g_activity[ctx->device];
@@ -190,6 +200,7 @@ static void end_ticketed_call(const mrs_context* ctx, hipStream_t s, uint32_t bl
     if (!a.event) return;
     if (hipEventRecord(a.event, s) == hipSuccess) {
         a.stream = s;
+        a.lineage = lineage;
         a.recorded = true;
     } else {
         (void)hipGetLastError();
@@ -667,7 +678,7 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
     plan->pass_plan_live = skip_passes;
     uint32_t xcd_block = 0;
     if (plan->desc.algo == MRS_ALGO_ONESWEEP) {
-        xcd_block = begin_ticketed_call(plan->ctx, s);
+        xcd_block = begin_ticketed_call(plan->ctx, s, plan->lineage);
         const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
         const size_t zero = kControlBytes + align_up(region * plan->num_passes, 256);
         // a primed plan keeps its histograms: only the ticket counters and the status words are cleared
@@ -730,7 +741,7 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
             if (int rc = mark(plan, "onesweep_pass", s)) return rc;
         }
     }
-    if (plan->desc.algo == MRS_ALGO_ONESWEEP) end_ticketed_call(plan->ctx, s, xcd_block);
+    if (plan->desc.algo == MRS_ALGO_ONESWEEP) end_ticketed_call(plan->ctx, s, xcd_block, plan->lineage);
     return MRS_OK;
 }
 
@@ -987,6 +998,8 @@ int partition_internal(mrs_plan* plan, uint64_t n, const void* keys_in, const vo
                                    hipMemcpyDeviceToDevice, s));
     } else {
         if (num_splitters) return fail(MRS_ERR_INVALID_ARGUMENT, "partition: splitters need precomputed class offsets");
+        (void)splitters_dev;
+        (void)exact_mask;
         GlobalHistArgs h{};
         h.keys = keys_in;
         h.n = n32;
@@ -1026,10 +1039,10 @@ int partition_pass(mrs_plan* plan, uint64_t n, const void* keys_in, const void* 
     a.status = plan->status;
     a.wide_status = plan->status_word_bytes == 8;
     a.tile_counter = plan->control->tile_counter[0];
-    a.xcd_block = begin_ticketed_call(plan->ctx, s);
+    a.xcd_block = begin_ticketed_call(plan->ctx, s, plan->lineage);
     a.error_flag = plan->error_flag;
     if (int rc = launch_pass(plan, kModeOnesweep, a, s)) return rc;
-    end_ticketed_call(plan->ctx, s, a.xcd_block);
+    end_ticketed_call(plan->ctx, s, a.xcd_block, plan->lineage);
     return MRS_OK;
 }
 

@@ -365,7 +365,14 @@ struct mrs_dist {
     mrs_dist_desc desc{};
     uint64_t tolerance = 0, recv_capacity = 0;
     mrs_plan* part_plan = nullptr;
-    mrs_plan* sort_plan = nullptr;
+    // Every rank receives its share in `chunks` pieces of consecutive key ranges, exchanged one
+    // after the other: the local sort of a piece (on `side`) runs beside the exchange of the next.
+    int chunks = 1;
+    uint64_t chunk_capacity = 0;
+    mrs_plan* sort_plan[2] = {nullptr, nullptr};
+    hipStream_t side = nullptr;
+    hipEvent_t arrived[2] = {nullptr, nullptr};
+    hipEvent_t sorted_all = nullptr;
     size_t key_bytes = 4, val_bytes = 0;
     // device memory owned by the handle
     char* small = nullptr;  // [hist_local][hist_global][hist_all: world rows][PartitionTables]
@@ -469,7 +476,12 @@ static void free_dist(mrs_dist* d)
 {
     if (!d) return;
     if (d->part_plan) (void)mrs_plan_destroy(d->part_plan);
-    if (d->sort_plan) (void)mrs_plan_destroy(d->sort_plan);
+    for (mrs_plan* p : d->sort_plan)
+        if (p) (void)mrs_plan_destroy(p);
+    if (d->side) (void)hipStreamDestroy(d->side);
+    for (hipEvent_t e : d->arrived)
+        if (e) (void)hipEventDestroy(e);
+    if (d->sorted_all) (void)hipEventDestroy(d->sorted_all);
     void* dev[] = {d->small, d->part_k, d->part_v, d->recv_k, d->recv_v, d->tmp_k, d->tmp_v};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -503,6 +515,17 @@ extern "C" int mrs_dist_create(mrs_context* ctx, mrs_comm* comm, const mrs_dist_
     d->desc = *desc;
     d->tolerance = desc->tolerance ? desc->tolerance : desc->n_local_max / 256;
     d->recv_capacity = desc->n_local_max + 2 * d->tolerance + 2;
+    if (desc->exchange_chunks < 0 || desc->exchange_chunks > 2) {
+        delete d;
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_create: exchange_chunks must be 0 (chosen here), 1 or 2");
+    }
+    // two pieces wherever that leaves the partition within its 31 key classes and there is a peer to overlap with
+    d->chunks = desc->exchange_chunks ? desc->exchange_chunks : ((comm->world >= 2 && comm->world <= kSplitMaxRanks / 2) ? 2 : 1);
+    if (d->chunks * comm->world > kSplitMaxRanks) {
+        delete d;
+        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_create: exchange_chunks x world must not exceed %d", kSplitMaxRanks);
+    }
+    d->chunk_capacity = (desc->n_local_max + d->chunks - 1) / d->chunks + 2 * d->tolerance + 2;
     d->key_bytes = 4u * desc->key_words;
     d->val_bytes = desc->payload_bytes;
     if (d->recv_capacity >= 0xFFFFFFFFull) {
@@ -524,8 +547,18 @@ extern "C" int mrs_dist_create(mrs_context* ctx, mrs_comm* comm, const mrs_dist_
     pd.algo = MRS_ALGO_ONESWEEP;
     pd.tile_items = 0;
     if (int rc = mrs_plan_create(ctx, &pd, &d->part_plan)) return bail(rc);
-    pd.n = d->recv_capacity;
-    if (int rc = mrs_plan_create(ctx, &pd, &d->sort_plan)) return bail(rc);
+    pd.n = d->chunks == 1 ? d->recv_capacity : d->chunk_capacity;
+    for (int c = 0; c < d->chunks; ++c)
+        if (int rc = mrs_plan_create(ctx, &pd, &d->sort_plan[c])) return bail(rc);
+    d->part_plan->lineage = d;
+    for (int c = 0; c < d->chunks; ++c) d->sort_plan[c]->lineage = d;
+    if (d->chunks > 1) {
+        if (hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&d->arrived[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d->arrived[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d->sorted_all, hipEventDisableTiming) != hipSuccess)
+            return bail(fail(MRS_ERR_HIP, "mrs_dist_create: stream or event creation failed"));
+    }
     const size_t rows = static_cast<size_t>(comm->world) + 2;
     const size_t small_bytes = rows * kHistWords * sizeof(uint64_t) + sizeof(PartitionTables);
     auto dev_alloc = [&](void** p, size_t bytes) {
@@ -554,8 +587,10 @@ extern "C" int mrs_dist_create(mrs_context* ctx, mrs_comm* comm, const mrs_dist_
     mrs_plan_info pi{};
     (void)mrs_plan_get_info(d->part_plan, &pi);
     d->device_bytes += pi.temp_bytes;
-    (void)mrs_plan_get_info(d->sort_plan, &pi);
-    d->device_bytes += pi.temp_bytes;
+    for (int c = 0; c < d->chunks; ++c) {
+        (void)mrs_plan_get_info(d->sort_plan[c], &pi);
+        d->device_bytes += pi.temp_bytes;
+    }
     *out = d;
     return MRS_OK;
 }
@@ -575,7 +610,7 @@ extern "C" int mrs_dist_set_timing(mrs_dist* dist, int enable)
         for (hipEvent_t& e : dist->marks) MRS_HIP_TRY(hipEventCreate(&e));
     dist->timing = enable != 0;
     dist->marks_valid = false;
-    return mrs_plan_set_timing(dist->sort_plan, enable);
+    return mrs_plan_set_timing(dist->sort_plan[dist->chunks - 1], enable);
 }
 
 extern "C" int mrs_dist_get_info(mrs_dist* dist, mrs_dist_info* info)
@@ -594,7 +629,7 @@ extern "C" int mrs_dist_get_info(mrs_dist* dist, mrs_dist_info* info)
         float ms[kMaxPasses * 4 + 8];
         char labels[(kMaxPasses * 4 + 8) * 32];
         int count = 0;
-        if (int rc = mrs_plan_get_timings(dist->sort_plan, kMaxPasses * 4 + 8, ms, labels, &count)) return rc;
+        if (int rc = mrs_plan_get_timings(dist->sort_plan[dist->chunks - 1], kMaxPasses * 4 + 8, ms, labels, &count)) return rc;
         float sum = 0.f;
         uint32_t passes = 0;
         for (int i = 0; i < count; ++i)
@@ -613,7 +648,8 @@ extern "C" int mrs_dist_check(mrs_dist* dist, void* stream)
     clear_error();
     if (!dist) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_check: null handle");
     if (int rc = mrs_plan_check(dist->part_plan, stream)) return rc;
-    if (int rc = mrs_plan_check(dist->sort_plan, stream)) return rc;
+    for (int c = 0; c < dist->chunks; ++c)
+        if (int rc = mrs_plan_check(dist->sort_plan[c], stream)) return rc;
     return dist->comm->check_async();
 }
 
@@ -644,7 +680,8 @@ extern "C" int mrs_dist_sort_pairs(mrs_dist* dist, uint64_t n_local, const void*
     if (d->timing) MRS_HIP_TRY(hipEventRecord(d->marks[0], s));
 
     // ---- 1-3. histograms, collectives, cuts -------------------------------------------------
-    Splitter sp(P, d->desc.end_bit, d->tolerance);
+    const int K = d->chunks;  // destination slices per rank
+    Splitter sp(P, P * K, d->desc.end_bit, d->tolerance);
     uint32_t shift = 0, bits = 0;
     std::vector<uint64_t> prefixes;
     uint64_t* h_global = d->h_hist;
@@ -698,18 +735,29 @@ extern "C" int mrs_dist_sort_pairs(mrs_dist* dist, uint64_t n_local, const void*
         if (sp.exact(r)) exact_mask |= 1u << r;
     d->last_exact_cuts = static_cast<uint32_t>(__builtin_popcount(exact_mask));
     // every rank can see every rank's load: all fail together, before any exchange
-    for (int r = 0; r < P; ++r)
-        if (sp.recv_total(r) > d->recv_capacity)
+    for (int r = 0; r < P; ++r) {
+        uint64_t total = 0;
+        for (int c = 0; c < K; ++c) {
+            const uint64_t piece = sp.recv_total(r * K + c);
+            total += piece;
+            if (K > 1 && piece > d->chunk_capacity)
+                return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_sort_pairs: piece %d of rank %d would hold %llu pairs, above the capacity %llu "
+                                                      "(n_local_max is smaller than some rank's share of the total)",
+                            c, r, (unsigned long long)piece, (unsigned long long)d->chunk_capacity);
+        }
+        if (total > d->recv_capacity)
             return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_sort_pairs: rank %d would receive %llu pairs, above the capacity %llu "
                                                   "(n_local_max is smaller than some rank's share of the total)",
-                        r, (unsigned long long)sp.recv_total(r), (unsigned long long)d->recv_capacity);
-    const uint64_t n_recv = sp.recv_total(me);
+                        r, (unsigned long long)total, (unsigned long long)d->recv_capacity);
+    }
+    uint64_t n_recv = 0;
+    for (int c = 0; c < K; ++c) n_recv += sp.recv_total(me * K + c);
     if (d->timing) MRS_HIP_TRY(hipEventRecord(d->marks[1], s));
 
     // ---- 4. stable partition by destination --------------------------------------------------
     const void* send_k = keys_in;
     const void* send_v = vals_in;
-    if (P > 1 && n_local) {
+    if (P * K > 1 && n_local) {
         PartitionTables* t = d->h_tables;
         sp.bucket_table(t->map);
         for (int r = 0; r < sp.num_cuts(); ++r) {
@@ -717,48 +765,71 @@ extern "C" int mrs_dist_sort_pairs(mrs_dist* dist, uint64_t n_local, const void*
             else t->splitters[r] = sp.key(r);
         }
         sp.class_starts(me, t->class_starts);
+        // the slower pass that compares keys with the cut values is only needed if some bucket holds a cut
+        bool marked = false;
+        for (uint32_t b = 0; b < (1u << sp.top_bits()); ++b) marked = marked || t->map[b] == kMapBySplitters;
+        const uint32_t splitters_in_use = marked ? static_cast<uint32_t>(sp.num_cuts()) : 0u;
         MRS_HIP_TRY(hipMemcpyAsync(d->tables_dev, t, sizeof(PartitionTables), hipMemcpyHostToDevice, s));
         if (int rc = partition_internal(d->part_plan, n_local, keys_in, vals_in, d->part_k, d->part_v, sp.top_shift(),
-                                        sp.top_bits(), d->tables_dev->map, d->tables_dev->splitters,
-                                        static_cast<uint32_t>(sp.num_cuts()), exact_mask, d->tables_dev->class_starts, s))
+                                        sp.top_bits(), d->tables_dev->map, d->tables_dev->splitters, splitters_in_use,
+                                        exact_mask, d->tables_dev->class_starts, s))
             return rc;
         if (int rc = partition_pass(d->part_plan, n_local, keys_in, vals_in, d->part_k, d->part_v, sp.top_shift(),
-                                    sp.top_bits(), d->tables_dev->map, d->tables_dev->splitters,
-                                    static_cast<uint32_t>(sp.num_cuts()), exact_mask, false, s))
+                                    sp.top_bits(), d->tables_dev->map, d->tables_dev->splitters, splitters_in_use, exact_mask,
+                                    false, s))
             return rc;
         send_k = d->part_k;
         send_v = d->part_v;
     }
     if (d->timing) MRS_HIP_TRY(hipEventRecord(d->marks[2], s));
 
-    // ---- 5. exchange, received in source-rank order ------------------------------------------
-    uint64_t send_off[kSplitMaxRanks], send_cnt[kSplitMaxRanks], recv_off[kSplitMaxRanks], recv_cnt[kSplitMaxRanks];
-    uint64_t so = 0, ro = 0;
-    for (int p = 0; p < P; ++p) {
-        send_cnt[p] = sp.send_count(me, p);
-        send_off[p] = so;
-        so += send_cnt[p];
-        recv_cnt[p] = sp.send_count(p, me);
-        recv_off[p] = ro;
-        ro += recv_cnt[p];
-    }
-    ExchangeArrays x{};
-    x.send[0] = send_k;
-    x.recv[0] = d->recv_k;
-    x.elem_bytes[0] = d->key_bytes;
-    x.count = 1;
-    if (d->val_bytes) {
-        x.send[1] = send_v;
-        x.recv[1] = d->recv_v;
-        x.elem_bytes[1] = d->val_bytes;
-        x.count = 2;
-    }
-    if (int rc = comm->alltoallv(x, send_off, send_cnt, recv_off, recv_cnt, s)) return rc;
-    if (d->timing) MRS_HIP_TRY(hipEventRecord(d->marks[3], s));
-
-    // ---- 6. local sort -------------------------------------------------------------------------
+    // ---- 5-6. exchange piece by piece, received in source-rank order; local sort of each piece ----
+    // The slice of this rank is the concatenation of its K pieces (consecutive key ranges), so
+    // sorting each piece where it arrived leaves the whole slice sorted.  With K = 2 the sort of
+    // piece 0 runs on the side stream while piece 1 is still on the links.
     int in_b = 0;
-    if (int rc = sort_pairs_internal(d->sort_plan, n_recv, d->recv_k, d->recv_v, d->tmp_k, d->tmp_v, s, &in_b)) return rc;
+    uint64_t region = 0;  // first element of the piece in the receive buffers
+    for (int c = 0; c < K; ++c) {
+        uint64_t send_off[kSplitMaxRanks], send_cnt[kSplitMaxRanks], recv_off[kSplitMaxRanks], recv_cnt[kSplitMaxRanks];
+        uint64_t ro = region;
+        for (int p = 0; p < P; ++p) {
+            const int v = p * K + c;  // destination slice: piece c of rank p
+            send_cnt[p] = sp.send_count(me, v);
+            send_off[p] = v == 0 ? 0 : sp.boundary(v - 1, me);
+            recv_cnt[p] = sp.send_count(p, me * K + c);
+            recv_off[p] = ro;
+            ro += recv_cnt[p];
+        }
+        const uint64_t piece = ro - region;
+        ExchangeArrays x{};
+        x.send[0] = send_k;
+        x.recv[0] = d->recv_k;
+        x.elem_bytes[0] = d->key_bytes;
+        x.count = 1;
+        if (d->val_bytes) {
+            x.send[1] = send_v;
+            x.recv[1] = d->recv_v;
+            x.elem_bytes[1] = d->val_bytes;
+            x.count = 2;
+        }
+        if (int rc = comm->alltoallv(x, send_off, send_cnt, recv_off, recv_cnt, s)) return rc;
+        hipStream_t sort_stream = s;
+        if (K > 1) {
+            MRS_HIP_TRY(hipEventRecord(d->arrived[c], s));
+            MRS_HIP_TRY(hipStreamWaitEvent(d->side, d->arrived[c], 0));
+            sort_stream = d->side;
+        }
+        if (c == K - 1 && d->timing) MRS_HIP_TRY(hipEventRecord(d->marks[3], s));
+        auto at = [&](void* base, size_t elem) { return base ? static_cast<char*>(base) + region * elem : nullptr; };
+        if (int rc = sort_pairs_internal(d->sort_plan[c], piece, at(d->recv_k, d->key_bytes), at(d->recv_v, d->val_bytes),
+                                         at(d->tmp_k, d->key_bytes), at(d->tmp_v, d->val_bytes), sort_stream, &in_b))
+            return rc;
+        region = ro;
+    }
+    if (K > 1) {
+        MRS_HIP_TRY(hipEventRecord(d->sorted_all, d->side));
+        MRS_HIP_TRY(hipStreamWaitEvent(s, d->sorted_all, 0));
+    }
     if (d->timing) {
         MRS_HIP_TRY(hipEventRecord(d->marks[4], s));
         d->marks_valid = true;

@@ -134,6 +134,9 @@ struct mrs_plan {
     void* temp;
     size_t temp_bytes;
     bool owns_temp;  // temp came from hipMalloc in mrs_plan_create (false: the library's static scratch)
+    // Set by the sharded sort on its own plans: their calls are ordered by events across its two
+    // streams, so the guard against concurrent die-aware passes treats them as one stream.
+    const void* lineage;
     // three-kernel
     uint32_t* hist;          // [radix][max_tiles]
     uint32_t* scan_partials; // chunk sums of the scan

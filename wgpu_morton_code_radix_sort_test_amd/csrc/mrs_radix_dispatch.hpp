@@ -16,7 +16,7 @@ namespace mrs {
 // 32-bit keys with such payloads the large tiles 512 x 16 ... 1024 x 32.  RANK selects how keys are ranked inside a wave
 // (kRankMatch / kRankAtomic, see mrs_radix_pass.hpp); each value is compiled in a
 // translation unit of its own.
-template <int MODE, int RANK, bool MAP, int BITS, typename KeyT, typename ValT>
+template <int MODE, int RANK, int MAP, int BITS, typename KeyT, typename ValT>
 int launch_pass_shape(int threads, int kpt, const PassArgs& a, hipStream_t s)
 {
 #define MRS_SHAPE(T, K) \
@@ -47,13 +47,20 @@ int launch_pass_bits(int bits, int threads, int kpt, const PassArgs& a, hipStrea
 {
     // the bucket -> part table is only used by the partition pass (onesweep machinery)
     if constexpr (MODE == kModeOnesweep) {
+        if (a.digit_map && a.num_splitters) {
+            // only the sharded sort gets here, with 8-bit digits and payloads of at most 4 bytes
+            if constexpr (sizeof(ValT) <= 4) {
+                if (bits == 8) return launch_pass_shape<MODE, RANK, kMapTableAndSplitters, 8, KeyT, ValT>(threads, kpt, a, s);
+            }
+            return fail(MRS_ERR_UNSUPPORTED, "a partition by splitters needs 8-bit digits and a payload of at most 4 bytes");
+        }
         if (a.digit_map) {
-            if (bits == 4) return launch_pass_shape<MODE, RANK, true, 4, KeyT, ValT>(threads, kpt, a, s);
-            if (bits == 8) return launch_pass_shape<MODE, RANK, true, 8, KeyT, ValT>(threads, kpt, a, s);
+            if (bits == 4) return launch_pass_shape<MODE, RANK, kMapTable, 4, KeyT, ValT>(threads, kpt, a, s);
+            if (bits == 8) return launch_pass_shape<MODE, RANK, kMapTable, 8, KeyT, ValT>(threads, kpt, a, s);
         }
     }
-    if (bits == 4) return launch_pass_shape<MODE, RANK, false, 4, KeyT, ValT>(threads, kpt, a, s);
-    if (bits == 8) return launch_pass_shape<MODE, RANK, false, 8, KeyT, ValT>(threads, kpt, a, s);
+    if (bits == 4) return launch_pass_shape<MODE, RANK, kMapNone, 4, KeyT, ValT>(threads, kpt, a, s);
+    if (bits == 8) return launch_pass_shape<MODE, RANK, kMapNone, 8, KeyT, ValT>(threads, kpt, a, s);
     return fail(MRS_ERR_UNSUPPORTED, "digit_bits must be 4 or 8");
 }
 

@@ -109,13 +109,19 @@ __device__ __forceinline__ uint32_t splitter_class(KeyT k, const KeyT* split, ui
     return c;
 }
 
-template <bool MAP, typename KeyT>
+// MAP: 0 = the digit is the key's bit field; kMapTable = the bit field indexes a table of
+// digits; kMapTableAndSplitters = table entries equal to kMapBySplitters mark buckets that hold
+// a splitter, whose keys are compared one by one.  The last form puts a data-dependent branch
+// behind every table lookup (the lookups of a thread's keys no longer overlap), so the host
+// selects it only for tables that do contain the mark: skewed inputs of the sharded sort.
+enum MapMode { kMapNone = 0, kMapTable = 1, kMapTableAndSplitters = 2 };
+
+template <int MAP, typename KeyT>
 __device__ __forceinline__ uint32_t key_digit(KeyT k, const PassArgs& a)
 {
     uint32_t d = static_cast<uint32_t>(k >> a.shift) & a.mask;
-    if constexpr (MAP) {
-        d = a.digit_map[d];
-        // buckets that hold a splitter are marked in the table: their keys are compared one by one
+    if constexpr (MAP != kMapNone) d = a.digit_map[d];
+    if constexpr (MAP == kMapTableAndSplitters) {
         if (d == kMapBySplitters) d = splitter_class<KeyT>(k, static_cast<const KeyT*>(a.splitters), a.num_splitters, a.exact_mask);
     }
     return d;
@@ -324,7 +330,7 @@ struct PassShared {
 };
 
 // Everything after the tile id is known.  FULL = the tile has TILE valid elements.
-template <int MODE, int RANK, bool MAP, bool FULL, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT,
+template <int MODE, int RANK, int MAP, bool FULL, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT,
           typename ValT>
 __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS, THREADS, KPT, KeyT, ValT>& sh,
                                              const uint32_t tile, const uint32_t tile_valid)
@@ -661,7 +667,7 @@ __device__ __forceinline__ uint32_t die_local_tile(uint32_t wg, uint32_t num_til
 // 128 registers; the other shapes are left to the compiler.
 constexpr int pass_min_waves_per_simd(int threads, int kpt) { return threads == 512 && kpt == 32 ? 4 : 1; }
 
-template <int MODE, int RANK, bool MAP, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
+template <int MODE, int RANK, int MAP, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
 __device__ __forceinline__ void run_digit_pass(const PassArgs& a, PassShared<BITS, THREADS, KPT, KeyT, ValT>& sh)
 {
     using S = PassShared<BITS, THREADS, KPT, KeyT, ValT>;
@@ -697,13 +703,13 @@ __device__ __forceinline__ void run_digit_pass(const PassArgs& a, PassShared<BIT
         process_tile<MODE, RANK, MAP, false, StatusT>(a, sh, tile, remaining);
 }
 
-template <int MODE, int RANK, bool MAP, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
+template <int MODE, int RANK, int MAP, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
 __global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) void digit_pass_kernel(const PassArgs a)
 {
     using S = PassShared<BITS, THREADS, KPT, KeyT, ValT>;
     static_assert(THREADS % 64 == 0 && THREADS >= S::RADIX, "one thread per digit is required");
     __shared__ S sh;
-    if constexpr (MODE == kModeOnesweep && !MAP && sizeof(KeyT) == 8) {
+    if constexpr (MODE == kModeOnesweep && MAP == kMapNone && sizeof(KeyT) == 8) {
         // Sorts of 64-bit keys: the device decided after the histograms which passes run
         // and on which side their input lies (PassArgs::pass_plan).  The word is uniform.
         const uint32_t plan = a.pass_plan ? *a.pass_plan : 0u;
@@ -715,14 +721,16 @@ __global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) voi
         b.keys_out = other_side ? const_cast<void*>(a.keys_in) : a.keys_out;
         b.vals_out = other_side ? const_cast<void*>(a.vals_in) : a.vals_out;
         run_digit_pass<MODE, RANK, MAP, StatusT>(b, sh);
-    } else if constexpr (MAP) {
+    } else if constexpr (MAP != kMapNone) {
         // The digit table (at most kMaxMapEntries bytes) is read three times per key: keep it in
         // LDS.  The first barrier of run_digit_pass orders these stores before any lookup.
         __shared__ uint8_t s_map[kMaxMapEntries];
         __shared__ KeyT s_split[kMaxSplitters + 1];
         for (uint32_t j = threadIdx.x; j <= a.mask && j < kMaxMapEntries; j += THREADS) s_map[j] = a.digit_map[j];
-        if (threadIdx.x < a.num_splitters && threadIdx.x < kMaxSplitters)
-            s_split[threadIdx.x] = static_cast<const KeyT*>(a.splitters)[threadIdx.x];
+        if constexpr (MAP == kMapTableAndSplitters) {
+            if (threadIdx.x < a.num_splitters && threadIdx.x < kMaxSplitters)
+                s_split[threadIdx.x] = static_cast<const KeyT*>(a.splitters)[threadIdx.x];
+        }
         PassArgs b = a;
         b.digit_map = s_map;
         b.splitters = s_split;
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(THREADS, pass_min_waves_per_simd(THREADS, KPT)) voi
     }
 }
 
-template <int MODE, int RANK, bool MAP, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
+template <int MODE, int RANK, int MAP, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
 int launch_pass_cfg(const PassArgs& a, hipStream_t s)
 {
     // 32-bit status words hold counts below 2^30; the scatter mode has no status words

@@ -8,9 +8,11 @@
 
 namespace mrs {
 
-Splitter::Splitter(int world, int key_bits, uint64_t tolerance)
-    : world_(world), key_bits_(key_bits), tolerance_(tolerance), n_(world, 0), cuts_(world > 0 ? world - 1 : 0)
+Splitter::Splitter(int sources, int dests, int key_bits, uint64_t tolerance)
+    : world_(sources), dests_(dests), key_bits_(key_bits), tolerance_(tolerance), n_(sources, 0),
+      cuts_(dests > 0 ? dests - 1 : 0)
 {
+    const int world = sources;
     top_bits_ = key_bits < kSplitTopBits ? key_bits : kSplitTopBits;
     top_shift_ = key_bits - top_bits_;
     for (Cut& c : cuts_) {
@@ -68,7 +70,7 @@ int Splitter::feed(const uint64_t* counts)
         }
         for (int r = 0; r < num_cuts(); ++r) {
             // floor((r + 1) * N / P) without overflow: N < 2^36 in practice, P <= 16
-            cuts_[r].target = static_cast<uint64_t>((static_cast<unsigned __int128>(total_) * (r + 1)) / world_);
+            cuts_[r].target = static_cast<uint64_t>((static_cast<unsigned __int128>(total_) * (r + 1)) / dests_);
         }
         if (total_ == 0) {
             for (Cut& c : cuts_) c.placed = true;
@@ -150,7 +152,7 @@ int Splitter::feed(const uint64_t* counts)
 
 uint64_t Splitter::send_count(int src, int dst) const
 {
-    const uint64_t hi = dst == world_ - 1 ? n_[src] : boundary(dst, src);
+    const uint64_t hi = dst == dests_ - 1 ? n_[src] : boundary(dst, src);
     const uint64_t lo = dst == 0 ? 0 : boundary(dst - 1, src);
     return hi - lo;
 }

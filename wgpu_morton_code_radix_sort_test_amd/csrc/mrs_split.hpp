@@ -24,9 +24,12 @@ constexpr int kSplitMaxPrefixes = kSplitMaxRanks - 1;
 
 class Splitter {
 public:
-    // Keys are compared on their low `key_bits` bits (higher bits must be zero).  A cut may miss
-    // its ideal position by at most `tolerance` elements before the splitter descends a level.
-    Splitter(int world, int key_bits, uint64_t tolerance);
+    // `sources` ranks hold the input slices; the sorted order is cut into `dests` slices (a
+    // multiple of the ranks when every rank receives its share in several pieces).  Keys are
+    // compared on their low `key_bits` bits (higher bits must be zero).  A cut may miss its ideal
+    // position by at most `tolerance` elements before the splitter descends a level.
+    Splitter(int sources, int dests, int key_bits, uint64_t tolerance);
+    Splitter(int world, int key_bits, uint64_t tolerance) : Splitter(world, world, key_bits, tolerance) {}
 
     // The histogram wanted next: digit = (key >> shift) & ((1 << bits) - 1), counted separately for
     // each of `prefixes`, over the keys with (key >> (shift + bits)) == prefix (one empty prefix,
@@ -38,8 +41,9 @@ public:
     int feed(const uint64_t* counts);
 
     // ---- results (valid once next() returns false) ------------------------------------------
-    int world() const { return world_; }
-    int num_cuts() const { return world_ - 1; }
+    int world() const { return world_; }  // source ranks
+    int dests() const { return dests_; }
+    int num_cuts() const { return dests_ - 1; }
     uint64_t total() const { return total_; }
     uint64_t rank_size(int rank) const { return n_[rank]; }
     // Cut r (0-based, between destination r and r + 1): keys below key(r) go to destinations <= r.
@@ -50,7 +54,7 @@ public:
     uint64_t take(int r, int rank) const { return cuts_[r].take[rank]; }
     // Position of cut r in rank's slice once that slice is stably partitioned by key class.
     uint64_t boundary(int r, int rank) const { return cuts_[r].lt[rank] + cuts_[r].take[rank]; }
-    // Elements rank `src` sends to rank `dst`.
+    // Elements rank `src` sends to destination slice `dst`.
     uint64_t send_count(int src, int dst) const;
     uint64_t recv_total(int dst) const;
 
@@ -82,7 +86,7 @@ private:
     void level_geometry(int level, uint32_t* shift, uint32_t* bits) const;
     void place_all_when_empty();
 
-    int world_, key_bits_;
+    int world_, dests_, key_bits_;
     uint64_t tolerance_;
     uint32_t top_shift_, top_bits_;
     int level_ = 0;

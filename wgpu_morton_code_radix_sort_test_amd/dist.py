@@ -70,11 +70,11 @@ def _as_tensor(ptr, words, device):
 class DistributedSorter:
     """`mrs_dist`: rank `comm.rank`'s end of the sharded sort of (key, payload) pairs."""
 
-    def __init__(self, ctx, comm, n_local_max, key_words=1, payload_words=1, end_bit=None, tolerance=0):
+    def __init__(self, ctx, comm, n_local_max, key_words=1, payload_words=1, end_bit=None, tolerance=0, exchange_chunks=0):
         self.ctx, self.comm, self.lib = ctx, comm, ctx.lib
         self.key_words, self.payload_words = key_words, payload_words
         self.end_bit = 32 * key_words if end_bit is None else end_bit
-        desc = _lib.DistDesc(n_local_max, key_words, 4 * payload_words, self.end_bit, 0, tolerance)
+        desc = _lib.DistDesc(n_local_max, key_words, 4 * payload_words, self.end_bit, exchange_chunks, tolerance)
         h = ctypes.c_void_p()
         _lib.check(self.lib.mrs_dist_create(ctx._h, comm._h, ctypes.byref(desc), ctypes.byref(h)))
         self._h = h
