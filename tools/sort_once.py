@@ -18,6 +18,7 @@ import wgpu_morton_code_radix_sort_test_amd as mrs  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=28)
+    ap.add_argument("--n", type=int, default=0, help="element count (overrides --log2n)")
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--tile-items", type=int, default=0)
     ap.add_argument("--digit-bits", type=int, default=8)
@@ -31,7 +32,7 @@ def main():
                     help="sort (key, source index) and move each record of --payload-bytes once (mrs_sort_gather)")
     args = ap.parse_args()
     ctx = mrs.Context(0)
-    n = 1 << args.log2n
+    n = args.n or (1 << args.log2n)
     algo = mrs.ALGO_ONESWEEP if args.algo == "onesweep" else mrs.ALGO_THREE_KERNEL
     plan = mrs.SortPlan(ctx, n, key_words=args.key_words, payload_bytes=4 if args.gather else args.payload_bytes,
                         digit_bits=args.digit_bits, algo=algo, tile_items=args.tile_items)

@@ -553,11 +553,10 @@ extern "C" int mrs_dist_create(mrs_context* ctx, mrs_comm* comm, const mrs_dist_
     d->part_plan->lineage = d;
     for (int c = 0; c < d->chunks; ++c) d->sort_plan[c]->lineage = d;
     if (d->chunks > 1) {
-        // lowest priority: where the sort of one piece and the exchange of the next compete for a
-        // compute unit, the collective's few workgroups go first (the links are the scarcer resource)
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, least) != hipSuccess ||
+        // Default priority on purpose: a low-priority stream whose chained-scan pass holds compute
+        // units while it waits for tiles that the dispatcher keeps behind another stream's
+        // workgroups stalled two ranks sharing one GPU for minutes.
+        if (hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&d->arrived[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->arrived[1], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->sorted_all, hipEventDisableTiming) != hipSuccess)

@@ -65,7 +65,9 @@ struct StatusBits {
 // 32 = everything computed, but the output addresses are in tile order (the chain without the
 //      scatter pattern),
 // 64 = with 32: every address one element further (sequential, but no store is line-aligned),
-// 128 = with 32: aligned 256-byte segments, each sent to a pseudo-random place of the array.
+// 128 = with 32: aligned 256-byte segments, each sent to a pseudo-random place of the array,
+// 256 = with 32: the digit's base is still read from LDS and added, multiplied by a zero the
+//       compiler cannot see (the address keeps its dependency on two chained LDS reads).
 #ifndef MRS_ABLATE
 #define MRS_ABLATE 0
 #endif
@@ -228,6 +230,11 @@ __device__ __forceinline__ uint32_t window_reduce(const StatusT (&v)[J], uint32_
 #ifndef MRS_STORE_POLICY
 #define MRS_STORE_POLICY 0
 #endif
+// -DMRS_SCALAR_WRITE_OUT=1: diagnostic builds write four-byte elements back one per lane and
+// instruction, as every other element type is written.
+#ifndef MRS_SCALAR_WRITE_OUT
+#define MRS_SCALAR_WRITE_OUT 0
+#endif
 template <typename T>
 __device__ __forceinline__ void policy_store(T* p, const T& v)
 {
@@ -262,6 +269,17 @@ __device__ __forceinline__ void store_element(T* base, uint32_t index, const T& 
         policy_store(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + index * static_cast<uint32_t>(sizeof(T))), v);
     else
         policy_store(base + index, v);
+}
+// The same for a value that spans several elements of `elem_bytes` each: `index` counts elements,
+// so the address need only have the element's alignment (gfx950 serves the 16-byte store at any
+// 4-byte boundary).
+template <bool OFF32, typename T>
+__device__ __forceinline__ void store_element(T* base, uint32_t index, const T& v, uint32_t elem_bytes)
+{
+    if constexpr (OFF32)
+        policy_store(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + index * elem_bytes), v);
+    else
+        policy_store(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + static_cast<size_t>(index) * elem_bytes), v);
 }
 
 // Tile-local positions are below 2^16 (no tile shape exceeds 65536 elements), so two
@@ -566,26 +584,75 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     // The payload in the same slot goes to the same place; the digit of the slot (a
     // quarter of a register) is what is remembered of it.
     PackedDigits<KPT> slot_digit;
+    // Four-byte elements leave in groups of four consecutive slots per lane: one 16-byte LDS read,
+    // one look-up of the run's base and one 16-byte store (a wave writes 1 KiB per instruction,
+    // so fewer lines are touched twice) wherever the four slots lie in one digit's run, which the
+    // first and the last digit tell because slots are sorted by digit.  The few lanes whose group
+    // straddles a run boundary (about two per wave) store element by element.
+    constexpr bool VEC4 = sizeof(KeyT) == 4 && KPT % 4 == 0 && !(kAblate & ~(1 | 2 | 4 | 8 | 32)) && !MRS_SCALAR_WRITE_OUT;
+    if constexpr (VEC4) {
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        const uint32_t slot = i * THREADS + tid;
-        uint32_t d = 0;
-        if (FULL || slot < tile_valid) {
-            const KeyT k = stage_keys[slot];
-            d = key_digit<MAP>(k, a);
-            uint32_t g = sh.gbase[d] + slot;
-            if (kAblate & (3 | 32)) g = static_cast<uint32_t>(tile_base) + slot;
-            if (kAblate & 16) g = g < a.n ? g : slot;  // the estimate may overshoot the last run
-            if (kAblate & 64) g = g + 1 < a.n ? g + 1 : 0;
-            if (kAblate & 128) {
-                const uint32_t chunks = a.n >> 6;  // n is a multiple of 64 in the timing runs
-                g = ((g >> 6) * 2654435761u % chunks) * 64u + (g & 63u);
+        for (int j = 0; j < KPT / 4; ++j) {
+            const uint32_t s0 = (j * THREADS + tid) * 4u;
+            uint32_t d[4] = {0, 0, 0, 0};
+            if (FULL || s0 + 3 < tile_valid) {
+                const uint4 kk = *reinterpret_cast<const uint4*>(stage_keys + s0);
+                const KeyT k[4] = {kk.x, kk.y, kk.z, kk.w};
+                d[0] = key_digit<MAP>(k[0], a);
+                d[3] = key_digit<MAP>(k[3], a);
+                if (d[0] == d[3]) {
+                    d[1] = d[2] = d[0];
+                    uint32_t g = sh.gbase[d[0]] + s0;
+                    if (kAblate & (3 | 32)) g = static_cast<uint32_t>(tile_base) + s0;
+                    if (kAblate & 8) { keep_alive(kk); keep_alive(g); }
+                    else store_element<OFF32>(reinterpret_cast<uint4*>(keys_out), g, kk, 4u);
+                } else {
+                    d[1] = key_digit<MAP>(k[1], a);
+                    d[2] = key_digit<MAP>(k[2], a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t g = sh.gbase[d[e]] + s0 + e;
+                        if (kAblate & (3 | 32)) g = static_cast<uint32_t>(tile_base) + s0 + e;
+                        if (kAblate & 8) { keep_alive(k[e]); keep_alive(g); }
+                        else store_element<OFF32>(keys_out, g, k[e]);
+                    }
+                }
+            } else if (!FULL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (s0 + e < tile_valid) {
+                        const KeyT k = stage_keys[s0 + e];
+                        d[e] = key_digit<MAP>(k, a);
+                        store_element<OFF32>(keys_out, sh.gbase[d[e]] + s0 + e, k);
+                    }
+                }
             }
-            if (kAblate & 8) { keep_alive(k); keep_alive(g); }
-            else store_element<OFF32>(keys_out, g, k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) slot_digit.set_fresh(4 * j + e, d[e]);
+            if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bounds the registers in flight
         }
-        slot_digit.set_fresh(i, d);
-        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // bounds the registers in flight
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t slot = i * THREADS + tid;
+            uint32_t d = 0;
+            if (FULL || slot < tile_valid) {
+                const KeyT k = stage_keys[slot];
+                d = key_digit<MAP>(k, a);
+                uint32_t g = sh.gbase[d] + slot;
+                if (kAblate & (3 | 32)) g = static_cast<uint32_t>(tile_base) + slot + ((kAblate & 256) ? g * (a.num_tiles >> 31) : 0u);
+                if (kAblate & 16) g = g < a.n ? g : slot;  // the estimate may overshoot the last run
+                if (kAblate & 64) g = g + 1 < a.n ? g + 1 : 0;
+                if (kAblate & 128) {
+                    const uint32_t chunks = a.n >> 6;  // n is a multiple of 64 in the timing runs
+                    g = ((g >> 6) * 2654435761u % chunks) * 64u + (g & 63u);
+                }
+                if (kAblate & 8) { keep_alive(k); keep_alive(g); }
+                else store_element<OFF32>(keys_out, g, k);
+            }
+            slot_digit.set_fresh(i, d);
+            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // bounds the registers in flight
+        }
     }
 
     // ---- payload: same permutation ------------------------------------------------------
@@ -599,23 +666,56 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
             if (FULL || my_first + i * 64 < tile_valid) stage_vals[pos.get(i)] = val[i];
         __syncthreads();
         MRS_STAMP(14);
+        if constexpr (VEC4 && sizeof(ValT) == 4) {
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t slot = i * THREADS + tid;
-            if (FULL || slot < tile_valid) {
-                const ValT v = stage_vals[slot];
-                uint32_t g = sh.gbase[slot_digit.get(i)] + slot;
-                if (kAblate & (3 | 32)) g = static_cast<uint32_t>(tile_base) + slot;
-                if (kAblate & 16) g = g < a.n ? g : slot;
-                if (kAblate & 64) g = g + 1 < a.n ? g + 1 : 0;
-                if (kAblate & 128) {
-                    const uint32_t chunks = a.n >> 6;
-                    g = ((g >> 6) * 2654435761u % chunks) * 64u + (g & 63u);
+            for (int j = 0; j < KPT / 4; ++j) {
+                const uint32_t s0 = (j * THREADS + tid) * 4u;
+                if (FULL || s0 + 3 < tile_valid) {
+                    const uint4 vv = *reinterpret_cast<const uint4*>(stage_vals + s0);
+                    const uint32_t d0 = slot_digit.get(4 * j), d3 = slot_digit.get(4 * j + 3);
+                    if (d0 == d3) {
+                        uint32_t g = sh.gbase[d0] + s0;
+                        if (kAblate & (3 | 32)) g = static_cast<uint32_t>(tile_base) + s0;
+                        if (kAblate & 8) keep_alive(vv);
+                        else store_element<OFF32>(reinterpret_cast<uint4*>(vals_out), g, vv, 4u);
+                    } else {
+                        const uint32_t v[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            uint32_t g = sh.gbase[slot_digit.get(4 * j + e)] + s0 + e;
+                            if (kAblate & (3 | 32)) g = static_cast<uint32_t>(tile_base) + s0 + e;
+                            if (kAblate & 8) keep_alive(v[e]);
+                            else store_element<OFF32>(reinterpret_cast<uint32_t*>(vals_out), g, v[e]);
+                        }
+                    }
+                } else if (!FULL) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (s0 + e < tile_valid)
+                            store_element<OFF32>(vals_out, sh.gbase[slot_digit.get(4 * j + e)] + s0 + e, stage_vals[s0 + e]);
                 }
-                if (kAblate & 8) keep_alive(v);
-                else store_element<OFF32>(vals_out, g, v);
+                if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
-            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                // the slot numbering of the key loop above
+                const uint32_t slot = VEC4 ? ((i / 4) * THREADS + tid) * 4u + (i & 3) : i * THREADS + tid;
+                if (FULL || slot < tile_valid) {
+                    const ValT v = stage_vals[slot];
+                    uint32_t g = sh.gbase[slot_digit.get(i)] + slot;
+                    if (kAblate & (3 | 32)) g = static_cast<uint32_t>(tile_base) + slot + ((kAblate & 256) ? g * (a.num_tiles >> 31) : 0u);
+                    if (kAblate & 16) g = g < a.n ? g : slot;
+                    if (kAblate & 64) g = g + 1 < a.n ? g + 1 : 0;
+                    if (kAblate & 128) {
+                        const uint32_t chunks = a.n >> 6;
+                        g = ((g >> 6) * 2654435761u % chunks) * 64u + (g & 63u);
+                    }
+                    if (kAblate & 8) keep_alive(v);
+                    else store_element<OFF32>(vals_out, g, v);
+                }
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 #ifdef MRS_STAMPS
