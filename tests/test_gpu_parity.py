@@ -31,8 +31,10 @@ def test_generators_match_oracle(ctx, oracle):
         assert np.array_equal(u, oracle.gen_u32(9, 3, n))
 
 
-@pytest.mark.parametrize("n", [1, 3, 4, 5, 1023, 65536, 100003])
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1023, 4095, 4096, 4097, 65536, 100003, 4096 * 256, 4096 * 600 + 7])
 def test_morton_encode30_matches_oracle(ctx, oracle, n):
+    """Sizes on both sides of the encoder's 4096-point tile, one tile per workgroup, and more tiles
+    than workgroups (every workgroup loops, loading one tile ahead) with a ragged end."""
     xyz = oracle.gen_points(7, n)
     mn, mx = oracle.minmax3(xyz)
     keys, idx = ctx.morton_encode30(to_dev(xyz, ctx.device), mn, mx)
@@ -419,12 +421,13 @@ def test_sort_gather_output_feeds_a_bvh_builder(ctx, oracle, mrs, code_mask):
     plan.close()
 
 
-@pytest.mark.parametrize("bits,begin,end", [(8, 0, 32), (8, 0, 30), (4, 0, 30), (8, 3, 27)])
-def test_encode_for_sort_primes_the_plan(ctx, oracle, mrs, bits, begin, end):
+@pytest.mark.parametrize("bits,begin,end,n", [(8, 0, 32, 200003), (8, 0, 30, 200003), (4, 0, 30, 200003),
+                                              (8, 3, 27, 200003), (8, 0, 30, 4096 * 530 + 11)])
+def test_encode_for_sort_primes_the_plan(ctx, oracle, mrs, bits, begin, end, n):
     """The encoder that leaves the digit histograms in the plan: same keys as the plain encoder,
     and the sort that follows (which then skips its histogram launch) gives the checker's result;
-    a later sort of other keys with the same plan is not affected."""
-    n = 200003
+    a later sort of other keys with the same plan is not affected.  The largest size has more
+    4096-point tiles than the GPU has CUs, so every workgroup of the encoder counts several."""
     xyz = oracle.gen_points(5, n)
     mn, mx = oracle.minmax3(xyz)
     rk, ri = oracle.morton_encode30(xyz, mn, mx)

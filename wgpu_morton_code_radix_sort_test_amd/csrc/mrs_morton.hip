@@ -117,15 +117,27 @@ struct EncodeHistogram {
     uint32_t begin_bit, end_bit, bits, num_passes;
 };
 
-// Each thread encodes 4 consecutive points = 48 bytes = three 16-byte loads.
+// Each thread encodes 4 consecutive points = 48 bytes.  A workgroup of 1024 threads takes a tile of
+// 4096 points: its 48 KiB are read as three rows of 16 KiB, one fully coalesced 16-byte load per
+// thread and row (a wave reads 1 KiB of consecutive addresses instead of 64 pieces 48 bytes apart),
+// and handed to the threads through LDS.  One workgroup per CU, nontemporal loads and stores (the
+// stream is touched once): 0.90 ms against 1.07 ms for direct strided loads at 2^28 points.
+// The points after the last full tile take the direct path in one workgroup.
+constexpr int kEncode30Threads = 1024;
+constexpr int kEncode30TilePoints = kEncode30Threads * 4;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <bool HIST>
-__global__ __launch_bounds__(256) void morton_encode30_kernel(const float* __restrict__ xyz, unsigned long long n,
-                                                               const Bounds3 b, uint32_t* __restrict__ keys,
-                                                               uint32_t* __restrict__ idx, const EncodeHistogram h)
+__global__ __launch_bounds__(kEncode30Threads) void morton_encode30_kernel(
+    const float* __restrict__ xyz, unsigned long long n, const Bounds3 b, uint32_t* __restrict__ keys,
+    uint32_t* __restrict__ idx, const EncodeHistogram h)
 {
+    __shared__ f32x4 s_tile[2][3 * kEncode30Threads];
     __shared__ uint32_t s_hist[HIST ? 1024 : 1];  // 4 x 256 or 8 x 16 counters (32-bit keys)
     if constexpr (HIST) {
-        for (int j = threadIdx.x; j < 1024; j += 256) s_hist[j] = 0;
+        s_hist[threadIdx.x] = 0;
         __syncthreads();
     }
     auto count = [&](uint32_t k) {
@@ -136,23 +148,7 @@ __global__ __launch_bounds__(256) void morton_encode30_kernel(const float* __res
         }
     };
     const float ext[3] = {b.mx[0] - b.mn[0], b.mx[1] - b.mn[1], b.mx[2] - b.mn[2]};
-    const unsigned long long groups = (n + 3) / 4;
-    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256;
-    for (unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * 256 + threadIdx.x; g < groups;
-         g += stride) {
-        const unsigned long long first = g * 4;
-        float f[12];
-        if (first + 4 <= n) {
-            const float4* p = reinterpret_cast<const float4*>(xyz + first * 3);
-            const float4 a0 = p[0], a1 = p[1], a2 = p[2];
-            f[0] = a0.x; f[1] = a0.y; f[2] = a0.z; f[3] = a0.w;
-            f[4] = a1.x; f[5] = a1.y; f[6] = a1.z; f[7] = a1.w;
-            f[8] = a2.x; f[9] = a2.y; f[10] = a2.z; f[11] = a2.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 12; ++j) f[j] = first * 3 + j < n * 3 ? xyz[first * 3 + j] : 0.0f;
-        }
-        uint32_t k[4];
+    auto encode4 = [&](const float (&f)[12], uint32_t (&k)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint32_t u[3];
@@ -163,15 +159,50 @@ __global__ __launch_bounds__(256) void morton_encode30_kernel(const float* __res
             }
             k[q] = (spread10(u[0]) << 2) | (spread10(u[1]) << 1) | spread10(u[2]);
         }
-        if (first + 4 <= n) {
-            *reinterpret_cast<uint4*>(keys + first) = make_uint4(k[0], k[1], k[2], k[3]);
-            const uint32_t i0 = static_cast<uint32_t>(first);
-            *reinterpret_cast<uint4*>(idx + first) = make_uint4(i0, i0 + 1, i0 + 2, i0 + 3);
-            if constexpr (HIST) {
+    };
+
+    const unsigned long long full_tiles = n / kEncode30TilePoints;
+    auto load_rows = [&](unsigned long long tile, f32x4 (&row)[3]) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(xyz) + tile * (3 * kEncode30Threads);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) count(k[q]);
-            }
-        } else {
+        for (int r = 0; r < 3; ++r) row[r] = __builtin_nontemporal_load(p + r * kEncode30Threads + threadIdx.x);
+    };
+    f32x4 row[3];
+    if (blockIdx.x < full_tiles) load_rows(blockIdx.x, row);
+    int buf = 0;
+    for (unsigned long long tile = blockIdx.x; tile < full_tiles; tile += gridDim.x, buf ^= 1) {
+        // two LDS tiles: a thread that is still reading this one cannot be overtaken by a writer
+        // of the tile after the next, which has to pass the next barrier first
+        f32x4* t = s_tile[buf];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) t[r * kEncode30Threads + threadIdx.x] = row[r];
+        __syncthreads();
+        // the next tile's loads are in flight while this one is encoded
+        if (tile + gridDim.x < full_tiles) load_rows(tile + gridDim.x, row);
+        const f32x4 a0 = t[threadIdx.x * 3], a1 = t[threadIdx.x * 3 + 1], a2 = t[threadIdx.x * 3 + 2];
+        const float f[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+        uint32_t k[4];
+        encode4(f, k);
+        const unsigned long long first = tile * kEncode30TilePoints + threadIdx.x * 4u;
+        const uint32_t i0 = static_cast<uint32_t>(first);
+        const u32x4 kv = {k[0], k[1], k[2], k[3]};
+        const u32x4 iv = {i0, i0 + 1, i0 + 2, i0 + 3};
+        __builtin_nontemporal_store(kv, reinterpret_cast<u32x4*>(keys + first));
+        __builtin_nontemporal_store(iv, reinterpret_cast<u32x4*>(idx + first));
+        if constexpr (HIST) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) count(k[q]);
+        }
+    }
+    // the ragged end: fewer than 4096 points, in the workgroup whose turn it would have been
+    if (blockIdx.x == full_tiles % gridDim.x) {
+        const unsigned long long first = full_tiles * kEncode30TilePoints + threadIdx.x * 4u;
+        if (first < n) {
+            float f[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) f[j] = first * 3 + j < n * 3 ? xyz[first * 3 + j] : 0.0f;
+            uint32_t k[4];
+            encode4(f, k);
             for (int q = 0; q < 4; ++q)
                 if (first + q < n) {
                     keys[first + q] = k[q];
@@ -182,11 +213,18 @@ __global__ __launch_bounds__(256) void morton_encode30_kernel(const float* __res
     }
     if constexpr (HIST) {
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < (h.num_passes << h.bits); j += 256) {
-            const uint32_t c = s_hist[j];
-            if (c) atomicAdd(&h.ghist[j], c);
+        if (threadIdx.x < (h.num_passes << h.bits)) {
+            const uint32_t c = s_hist[threadIdx.x];
+            if (c) atomicAdd(&h.ghist[threadIdx.x], c);
         }
     }
+}
+
+// One workgroup per CU at most; fewer when there are fewer tiles (the ragged end counts as one).
+static unsigned encode30_grid(unsigned long long n, int num_cus)
+{
+    const unsigned long long tiles = (n + kEncode30TilePoints - 1) / kEncode30TilePoints;
+    return static_cast<unsigned>(tiles < static_cast<unsigned long long>(num_cus) ? (tiles ? tiles : 1) : num_cus);
 }
 
 // ---- generators: splitmix64-style counter hash -------------------------------------------
@@ -276,7 +314,7 @@ extern "C" int mrs_morton_encode30(mrs_context* ctx, const float* xyz_dev, uint6
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30: buffers must be 16-byte aligned");
     Bounds3 b;
     for (int c = 0; c < 3; ++c) { b.mn[c] = mn[c]; b.mx[c] = mx[c]; }
-    hipLaunchKernelGGL(morton_encode30_kernel<false>, dim3(grid_for((n + 3) / 4, ctx->num_cus)), dim3(256), 0,
+    hipLaunchKernelGGL(morton_encode30_kernel<false>, dim3(encode30_grid(n, ctx->num_cus)), dim3(kEncode30Threads), 0,
                        static_cast<hipStream_t>(stream), xyz_dev, static_cast<unsigned long long>(n), b, keys_dev,
                        idx_dev, EncodeHistogram{});
     MRS_CHECK_LAUNCH("morton_encode30_kernel");
@@ -293,16 +331,14 @@ int launch_encode30_with_histogram(int num_cus, const float* xyz_dev, uint64_t n
     if ((reinterpret_cast<uintptr_t>(xyz_dev) | reinterpret_cast<uintptr_t>(keys_dev) |
          reinterpret_cast<uintptr_t>(idx_dev)) & 15u)
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30_for_sort: buffers must be 16-byte aligned");
+    if ((static_cast<uint64_t>(num_passes) << bits) > 1024)
+        return fail(MRS_ERR_UNSUPPORTED, "mrs_morton_encode30_for_sort: more than 1024 digit counters");
     Bounds3 b;
     for (int c = 0; c < 3; ++c) { b.mn[c] = mn[c]; b.mx[c] = mx[c]; }
     const EncodeHistogram h{ghist, begin_bit, end_bit, bits, num_passes};
-    // fewer, longer-lived workgroups than the plain encoder: each ends with up to 1024 global atomics
-    uint64_t blocks = ((n + 3) / 4 + 256 * 8 - 1) / (256 * 8);
-    const uint64_t cap = static_cast<uint64_t>(num_cus) * 16;
-    if (blocks > cap) blocks = cap;
-    if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(morton_encode30_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, xyz_dev,
-                       static_cast<unsigned long long>(n), b, keys_dev, idx_dev, h);
+    // every workgroup ends with up to 1024 global atomics: one per CU keeps that to 256 K per call
+    hipLaunchKernelGGL(morton_encode30_kernel<true>, dim3(encode30_grid(n, num_cus)), dim3(kEncode30Threads), 0, s,
+                       xyz_dev, static_cast<unsigned long long>(n), b, keys_dev, idx_dev, h);
     MRS_CHECK_LAUNCH("morton_encode30_kernel<histogram>");
     return MRS_OK;
 }
