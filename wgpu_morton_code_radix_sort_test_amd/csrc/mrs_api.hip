@@ -237,11 +237,11 @@ static int launch_global_hist(const mrs_plan* p, const GlobalHistArgs& a, hipStr
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     // The sorts use the kernel with bank-spread counters: 1024 threads and 64 KiB of LDS per
-    // workgroup, two per compute unit, at least 4 vectors per thread (MRS_HIST_PLAIN=1: A/B aid;
-    // MRS_HIST_BANKED_PER_CU: tuning aid).
+    // workgroup, one per compute unit (two measured 2-3 % slower), at least 4 vectors per thread
+    // (MRS_HIST_PLAIN=1: A/B aid; MRS_HIST_BANKED_PER_CU: tuning aid).
     static const bool plain = std::getenv("MRS_HIST_PLAIN") != nullptr;
     static const uint64_t banked_per_cu =
-        std::getenv("MRS_HIST_BANKED_PER_CU") ? std::atoi(std::getenv("MRS_HIST_BANKED_PER_CU")) : 2;
+        std::getenv("MRS_HIST_BANKED_PER_CU") ? std::atoi(std::getenv("MRS_HIST_BANKED_PER_CU")) : 1;
     uint64_t banked = 0;
     if (!plain) {
         banked = (a.n / vec + 1024 * 4 - 1) / (1024 * 4);
