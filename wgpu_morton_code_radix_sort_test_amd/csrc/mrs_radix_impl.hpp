@@ -14,6 +14,11 @@ namespace mrs {
 // ---- per-tile digit histogram, digit-major (three-kernel pass) ------------------
 // radix_sort_compute_histogram, src/shaders/radix_sort_histogram.wgsl:42-60, for
 // a tile of `tile_items` keys instead of 256.
+// Every counter is kept in R copies, copy = lane % R, so that the lanes of one LDS atomic spread
+// over R banks whatever their digits are (see BankedHistogram below): R = 16 or 32 for tiles of
+// 8192 keys or more, fewer for small tiles, whose time would go into clearing and adding up the
+// copies.  A tile whose keys start on a 16-byte boundary is read with nontemporal 16-byte loads,
+// four in flight per thread.
 template <int BITS, typename KeyT>
 __global__ __launch_bounds__(256) void block_histogram_kernel(const KeyT* __restrict__ keys, uint32_t n,
                                                               uint32_t tile_items, uint32_t num_tiles,
@@ -21,18 +26,49 @@ __global__ __launch_bounds__(256) void block_histogram_kernel(const KeyT* __rest
                                                               uint32_t* __restrict__ hist)
 {
     constexpr int RADIX = 1 << BITS;
-    __shared__ uint32_t s_hist[RADIX];
+    constexpr int RMAX = RADIX >= 256 ? 16 : 32;
+    constexpr int VEC = 16 / sizeof(KeyT);
+    constexpr int UNROLL = 4;
+    __shared__ uint32_t s_hist[RADIX * RMAX];
     const uint32_t tile = blockIdx.x;
-    for (int j = threadIdx.x; j < RADIX; j += 256) s_hist[j] = 0;
+    const uint32_t R = tile_items >= 8192 ? RMAX : (tile_items >= 2048 ? 4 : 1);  // a power of two
+    for (uint32_t j = threadIdx.x; j < RADIX * R; j += 256) s_hist[j] = 0;
     __syncthreads();
+    const uint32_t copy = threadIdx.x & (R - 1);
+    auto count = [&](KeyT k) { atomicAdd(&s_hist[(static_cast<uint32_t>(k >> shift) & mask) * R + copy], 1u); };
     const unsigned long long base = static_cast<unsigned long long>(tile) * tile_items;
     const unsigned long long end = base + tile_items < n ? base + tile_items : n;
-    for (unsigned long long i = base + threadIdx.x; i < end; i += 256) {
-        const uint32_t d = static_cast<uint32_t>(keys[i] >> shift) & mask;
-        atomicAdd(&s_hist[d], 1u);
+    unsigned long long i = base;
+    if ((reinterpret_cast<uintptr_t>(keys + base) & 15u) == 0) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* __restrict__ vkeys = reinterpret_cast<const u32x4*>(keys + base);
+        const unsigned long long nvec = (end - base) / VEC;
+        auto count_vec = [&](const u32x4& x) {
+            if constexpr (sizeof(KeyT) == 4) {
+                count(x.x); count(x.y); count(x.z); count(x.w);
+            } else {
+                count(static_cast<KeyT>(x.x) | (static_cast<KeyT>(x.y) << 32));
+                count(static_cast<KeyT>(x.z) | (static_cast<KeyT>(x.w) << 32));
+            }
+        };
+        unsigned long long v = threadIdx.x;
+        for (; v + (UNROLL - 1) * 256 < nvec; v += UNROLL * 256) {
+            u32x4 x[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) x[u] = __builtin_nontemporal_load(vkeys + v + u * 256);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) count_vec(x[u]);
+        }
+        for (; v < nvec; v += 256) count_vec(__builtin_nontemporal_load(vkeys + v));
+        i = base + nvec * VEC;
     }
+    for (i += threadIdx.x; i < end; i += 256) count(keys[i]);
     __syncthreads();
-    for (int d = threadIdx.x; d < RADIX; d += 256) hist[static_cast<size_t>(d) * num_tiles + tile] = s_hist[d];
+    for (int d = threadIdx.x; d < RADIX; d += 256) {
+        uint32_t c = 0;
+        for (uint32_t r = 0; r < R; ++r) c += s_hist[d * R + ((r + d) & (R - 1))];  // rotated: threads on distinct banks
+        hist[static_cast<size_t>(d) * num_tiles + tile] = c;
+    }
 }
 
 // ---- global digit histograms of all passes in one read of the keys ---------------
