@@ -20,13 +20,15 @@ def main():
     ap.add_argument("--log2n", type=int, nargs="+", default=[12, 13, 14, 16, 18, 20, 22, 24])
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--key-words", type=int, default=1)
+    ap.add_argument("--payload-bytes", type=int, default=4)
+    ap.add_argument("--tile-items", type=int, default=0, help="0 = the plan's choice for the size")
     args = ap.parse_args()
     ctx = mrs.Context(0)
     for l in args.log2n:
         n = 1 << l
-        plan = mrs.SortPlan(ctx, n, key_words=args.key_words, payload_bytes=4)
+        plan = mrs.SortPlan(ctx, n, key_words=args.key_words, payload_bytes=args.payload_bytes, tile_items=args.tile_items)
         keys = ctx.generate_u32(7, 1, n * args.key_words)
-        idx = torch.arange(n, dtype=torch.int32, device=ctx.device)
+        idx = torch.arange(n * (args.payload_bytes // 4), dtype=torch.int32, device=ctx.device)
         ks = [keys.clone() for _ in range(args.reps)]
         vs = [idx.clone() for _ in range(args.reps)]
         kb, vb = torch.empty_like(keys), torch.empty_like(idx)
@@ -40,7 +42,8 @@ def main():
         torch.cuda.synchronize()
         plan.check()
         ms = e0.elapsed_time(e1) / args.reps
-        print(json.dumps({"log2n": l, "ms_per_sort": round(ms, 4), "gkeys_per_s": round(n / ms / 1e6, 3)}), flush=True)
+        print(json.dumps({"log2n": l, "ms_per_sort": round(ms, 4), "gkeys_per_s": round(n / ms / 1e6, 3),
+                          "tile_items": plan.info.tile_items}), flush=True)
         plan.close()
 
 

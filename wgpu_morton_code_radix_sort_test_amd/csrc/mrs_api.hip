@@ -65,11 +65,13 @@ bool config_supported(unsigned long long n, int key_words, int payload_bytes, in
         case 0:
             // Larger tiles scatter longer runs per digit and walk fewer tile status words, as
             // long as the input still yields several tiles per compute unit.
-            if (payload_bytes == 16) c = n >= (1ull << 23) ? KernelConfig{1024, 8} : (n >= (1ull << 20) ? KernelConfig{512, 8} : KernelConfig{256, 4});
-            else if (key_words == 2) c = n >= (1ull << 24) ? KernelConfig{1024, 16} : KernelConfig{512, 8};
-            else if (n >= (1ull << 25)) c = {1024, 32};
+            if (payload_bytes == 16) c = n >= (1ull << 20) ? KernelConfig{1024, 8} : (n >= (1ull << 18) ? KernelConfig{512, 8} : KernelConfig{256, 4});
+            else if (key_words == 2) c = n >= (1ull << 20) ? KernelConfig{1024, 16} : KernelConfig{512, 8};
+            // measured on whole sorts, back to back: 2^23 pairs 0.145 ms with 32768-key tiles
+            // (one per compute unit) against 0.184 with 16384; 2^18 0.060 ms with 4096 against 0.066
+            else if (n >= (1ull << 23)) c = {1024, 32};
             else if (n >= (1ull << 20)) c = {1024, 16};
-            else if (n >= (1ull << 17)) c = {512, 16};
+            else if (n >= (1ull << 19)) c = {512, 16};
             else c = {512, 8};
             break;
         case 256: c = {256, 1}; break;
@@ -107,8 +109,8 @@ constexpr size_t kControlBytes = (sizeof(OnesweepControl) + 255) / 256 * 256;
 // The temporary memory of a onesweep plan (error flag, control block, tile status words) for
 // inputs of at most kNoallocMaxN (u32 key, u32 payload) pairs, as one array of the code object:
 // every device the library runs on holds its own copy from the moment the code object is loaded
-// until the process ends.  2048 tiles is the most any n <= 2^26 yields (16384-key tiles below
-// 2^25 elements, 32768-key tiles from there on); 4 passes of 256 four-byte status words each.
+// until the process ends.  2048 tiles is the most any n <= 2^26 yields (32768-key tiles from
+// 2^23 elements on, at most 512 smaller tiles below); 4 passes of 256 four-byte status words each.
 constexpr uint64_t kNoallocMaxN = 1ull << 26;
 constexpr size_t kNoallocStatusBytes = 2048ull * 256 * 4 * 4;
 constexpr size_t kNoallocScratchBytes = 256 + kControlBytes + kNoallocStatusBytes;
