@@ -322,18 +322,22 @@ def main():
         extra["morton_encode30_GBps"] = 20.0 * n / (enc_ms * 1e-3) / 1e9
         # encode + sort as one pipeline, with the encoder that leaves the digit histograms in the
         # plan (the sort then skips its own read of the keys) and without; not part of `value`
-        for label, primed in (("encode_then_sort_ms", False), ("encode_for_sort_then_sort_ms", True)):
+        # ... and with no index array at all: the encoder writes keys only (12 + 4 B per point) and the
+        # sort makes the indices up in its first pass (mrs_sort_pairs_indexed, 64 B per pair)
+        for label, primed in (("encode_then_sort_ms", False), ("encode_for_sort_then_sort_ms", True),
+                              ("encode_keys_then_sort_indexed_ms", None)):
             times = []
             for _ in range(4):
                 p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 p0.record()
-                if primed:
+                if primed is None:
+                    ctx.morton_encode30(xyz, mn, mx, ek, keys_only=True)
+                    plan.sort_pairs_indexed(ek, ei, kb, vb)
+                elif primed:
                     plan.morton_encode30_for_sort(xyz, mn, mx, ek, ei)
-                else:
-                    ctx.morton_encode30(xyz, mn, mx, ek, ei)
-                if primed:
                     plan.sort_pairs_primed(ek, ei, kb, vb)
                 else:
+                    ctx.morton_encode30(xyz, mn, mx, ek, ei)
                     plan.sort_pairs(ek, ei, kb, vb)
                 p1.record()
                 torch.cuda.synchronize()

@@ -165,7 +165,9 @@ int mrs_morton_encode_lut(mrs_context* ctx, const void* uniforms_dev,
 /* 30-bit Morton key of a point cloud (xyz f32, 12 B per point), payload = the
  * point's index.  No counterpart in the reference: this is the key shape the
  * throughput metric is quoted on.  mn/mx are HOST pointers to 3 floats (the
- * scene bounds, as create_scene computes them on the CPU, src/main.rs:148-154). */
+ * scene bounds, as create_scene computes them on the CPU, src/main.rs:148-154).
+ * idx_dev may be NULL: only the keys are written (8 of the 20 bytes per point
+ * less), for a sort that makes the indices up itself (mrs_sort_pairs_indexed). */
 int mrs_morton_encode30(mrs_context* ctx, const float* xyz_dev, uint64_t n,
                         const float* mn, const float* mx, uint32_t* keys_dev,
                         uint32_t* idx_dev, void* stream);
@@ -185,6 +187,16 @@ int mrs_morton_encode30(mrs_context* ctx, const float* xyz_dev, uint64_t n,
  * result side stays the one reported here. */
 int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a,
                    void* keys_b, void* vals_b, void* stream, int* result_in_b);
+
+/* mrs_sort_pairs of (key, source index) pairs whose input payload is not stored anywhere: the
+ * payload of element i IS i, and the first pass makes it up instead of reading it (4 of the 16
+ * bytes per pair of that pass; no iota has to be written before the sort either).  The result
+ * is what mrs_sort_pairs gives for vals_a = 0, 1, ..., n-1.  `plan` must have payload_bytes == 4;
+ * vals_a is ping-pong space like vals_b and is never read before the library has written it.
+ * No counterpart in the reference, which carries the 16-byte TriangleIndices through every pass
+ * (src/shaders/radix_sort_index.wgsl:281-307); mrs_sort_gather is built on this call. */
+int mrs_sort_pairs_indexed(mrs_plan* plan, uint64_t n, void* keys_a, uint32_t* vals_a,
+                           void* keys_b, uint32_t* vals_b, void* stream, int* result_in_b);
 
 /* ---- single stages of one pass (MRS_ALGO_THREE_KERNEL plans) --------------- */
 /* radix_sort_compute_histogram (src/shaders/radix_sort_histogram.wgsl:42-60):
@@ -235,8 +247,9 @@ int mrs_sort_pairs_noalloc(mrs_context* ctx, uint64_t n, uint32_t* keys_a, uint3
 /* Sort by key, moving each wide record once: the variant the reference's own comments
  * anticipate for TriangleIndices (src/types.rs:26-36, src/shaders/radix_sort_index.wgsl:3-6)
  * instead of carrying 16 bytes through every pass (radix_sort_index.wgsl:281-307).  `plan` must
- * have payload_bytes == 4: (key, source index) pairs are sorted exactly as by mrs_sort_pairs, with
- * index_a filled with 0..n-1 first (index_a, index_b: u32[n] scratch), then
+ * have payload_bytes == 4: (key, source index) pairs are sorted exactly as by mrs_sort_pairs with
+ * index_a = 0..n-1 (mrs_sort_pairs_indexed: the indices are made up by the first pass, not
+ * written and read back; index_a, index_b: u32[n] scratch), then
  * records_out[j] = records_in[index[j]] for records of record_bytes (a positive multiple of 4).
  * Keys end in keys_a or keys_b as reported by result_in_b; records_out must not alias records_in.
  * The sorted source indices stay in index_a or index_b (same side as the keys).

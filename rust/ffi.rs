@@ -115,6 +115,11 @@ extern "C" {
     pub fn mrs_sort_pairs_primed(plan: *mut mrs_plan, n: u64, keys_a: *mut c_void, vals_a: *mut c_void,
                                  keys_b: *mut c_void, vals_b: *mut c_void, stream: *mut c_void,
                                  result_in_b: *mut c_int) -> c_int;
+    /// `mrs_sort_pairs` of (key, source index) pairs: the payload of input element i is i and is
+    /// made up by the first pass; `vals_a` is ping-pong space only.
+    pub fn mrs_sort_pairs_indexed(plan: *mut mrs_plan, n: u64, keys_a: *mut c_void, vals_a: *mut u32,
+                                  keys_b: *mut c_void, vals_b: *mut u32, stream: *mut c_void,
+                                  result_in_b: *mut c_int) -> c_int;
     pub fn mrs_sort_pairs_noalloc(ctx: *mut mrs_context, n: u64, keys_a: *mut u32, vals_a: *mut u32, keys_b: *mut u32,
                                   vals_b: *mut u32, begin_bit: i32, end_bit: i32, stream: *mut c_void,
                                   result_in_b: *mut c_int) -> c_int;

@@ -335,6 +335,82 @@ def test_sort_gather_matches_oracle(ctx, oracle, mrs, key_words, record_words):
         plan.close()
 
 
+@pytest.mark.parametrize("key_words,digit_bits,algo_name,dist,n,tile", [
+    (1, 8, "onesweep", "random", 1, 0), (1, 8, "onesweep", "few_distinct", 3000, 0),   # one-workgroup path
+    (2, 8, "onesweep", "random", 4096, 0), (1, 4, "onesweep", "random", 4000, 0),
+    (1, 8, "onesweep", "random", 4097, 0), (1, 8, "onesweep", "morton30", 300007, 0),
+    (1, 8, "onesweep", "random", 70001, 256), (1, 8, "onesweep", "few_distinct", 200003, 32768),
+    (1, 4, "onesweep", "random", 150001, 0), (1, 8, "three_kernel", "random", 150001, 0),
+    (1, 8, "three_kernel", "all_equal", 40000, 1024),
+    (2, 8, "onesweep", "random", 150001, 0), (2, 8, "three_kernel", "random", 50001, 0),
+    # 64-bit keys whose passes are partly or all identities: passes 0 and 1 must run all the same
+    (2, 8, "onesweep", "one_hot_digit", 150001, 0), (2, 8, "onesweep", "all_equal", 150001, 0),
+    (2, 8, "onesweep", "few_distinct", 150001, 0), (2, 8, "onesweep", "sorted", 100000, 0),
+])
+def test_sort_pairs_indexed_matches_oracle(ctx, oracle, mrs, key_words, digit_bits, algo_name, dist, n, tile):
+    """mrs_sort_pairs_indexed (the first pass makes the source indices up) gives what mrs_sort_pairs
+    gives for a payload of 0..n-1, whatever the payload buffers held before the call."""
+    end = 32 * key_words
+    algo = mrs.ALGO_ONESWEEP if algo_name == "onesweep" else mrs.ALGO_THREE_KERNEL
+    keys = make_keys(oracle, n, key_words, dist, seed=n)
+    iota = np.arange(n, dtype=np.uint32)
+    plan = mrs.SortPlan(ctx, n, key_words=key_words, payload_bytes=4, digit_bits=digit_bits, algo=algo, tile_items=tile)
+    ka = to_dev(keys, ctx.device)
+    kb = torch.full_like(ka, -1)
+    va = torch.full((n,), 0x5A5A5A5A, dtype=torch.int32, device=ctx.device)  # never read
+    vb = torch.full((n,), -1, dtype=torch.int32, device=ctx.device)
+    in_b = plan.sort_pairs_indexed(ka, va, kb, vb, n=n)
+    plan.check()
+    assert in_b == (plan.info.num_passes % 2 == 1)
+    rk, rv = oracle.stable_sort_pairs(keys, iota, n, key_words, 1, 0, end)
+    assert np.array_equal(to_u32(kb if in_b else ka)[: n * key_words], rk)
+    assert np.array_equal(to_u32(vb if in_b else va)[:n], rv)
+    if key_words == 2 and algo_name == "onesweep" and n > 4096:
+        left_out = plan.passes_left_out()
+        assert left_out & 3 == 0, "the passes that make the payload up and keep the count even must run"
+        assert bin(left_out).count("1") % 2 == 0
+        if dist == "all_equal":
+            assert left_out == 0b11111100
+    # a plain sort on the same plan afterwards is unaffected
+    ka2, va2 = to_dev(keys, ctx.device), to_dev(iota[::-1].copy(), ctx.device)
+    in_b = plan.sort_pairs(ka2, va2, kb, vb, n=n)
+    plan.check()
+    rk, rv = oracle.stable_sort_pairs(keys, iota[::-1].copy(), n, key_words, 1, 0, end)
+    assert np.array_equal(to_u32(kb if in_b else ka2)[: n * key_words], rk)
+    assert np.array_equal(to_u32(vb if in_b else va2)[:n], rv)
+    plan.close()
+
+
+def test_sort_pairs_indexed_rejects_other_payloads(ctx, mrs):
+    n = 1000
+    for pb in (0, 16):
+        plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=pb)
+        k = torch.zeros(n, dtype=torch.int32, device=ctx.device)
+        v = torch.zeros(4 * n, dtype=torch.int32, device=ctx.device)
+        with pytest.raises(mrs.MrsError):
+            plan.sort_pairs_indexed(k, v, torch.empty_like(k), torch.empty_like(v), n=n)
+        plan.close()
+
+
+def test_encode_keys_only_then_indexed_sort(ctx, oracle, mrs):
+    """The pipeline without a stored index array: the encoder writes keys only, the sort makes the
+    indices up.  Same keys and same sorted pairs as the two-array pipeline."""
+    n = 4096 * 300 + 77
+    xyz = oracle.gen_points(3, n)
+    mn, mx = oracle.minmax3(xyz)
+    rk, ri = oracle.morton_encode30(xyz, mn, mx)
+    keys, idx = ctx.morton_encode30(to_dev(xyz, ctx.device), mn, mx, keys_only=True)
+    assert idx is None
+    assert np.array_equal(to_u32(keys), rk)
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, end_bit=30)
+    va, kb, vb = (torch.full((n,), -1, dtype=torch.int32, device=ctx.device) for _ in range(3))
+    in_b = plan.sort_pairs_indexed(keys, va, kb, vb)
+    plan.check()
+    sk, sv = oracle.stable_sort_pairs(rk, ri, n, 1, 1, 0, 30)
+    assert np.array_equal(to_u32(kb if in_b else keys), sk) and np.array_equal(to_u32(vb if in_b else va), sv)
+    plan.close()
+
+
 def _karras_tree(codes, key_bits):
     """Binary radix tree over sorted codes (Karras 2012: determineRange + findSplit), with the
     leaf number breaking ties between equal codes.  Returns (left, right, first, last) per internal

@@ -101,6 +101,7 @@ SIGNATURES = {
     "mrs_sort_pairs": (ctypes.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int)]),
     "mrs_morton_encode30_for_sort": (ctypes.c_int, [_vp, _vp, _u64, _fp, _fp, _vp, _vp, _vp]),
     "mrs_sort_pairs_primed": (ctypes.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int)]),
+    "mrs_sort_pairs_indexed": (ctypes.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int)]),
     "mrs_sort_pairs_noalloc": (ctypes.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, ctypes.POINTER(ctypes.c_int)]),
     "mrs_sort_gather": (ctypes.c_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, ctypes.POINTER(ctypes.c_int)]),
     "mrs_histogram": (ctypes.c_int, [_vp, _u64, _vp, _u32, _vp, _vp]),

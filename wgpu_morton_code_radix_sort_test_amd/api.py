@@ -95,22 +95,23 @@ class Context:
             pass
 
     # ---- Morton encoders -------------------------------------------------
-    def morton_encode30(self, xyz, mn, mx, keys_out=None, idx_out=None, stream=None):
-        """30-bit Morton keys + index payload of an [n, 3] f32 point tensor."""
+    def morton_encode30(self, xyz, mn, mx, keys_out=None, idx_out=None, stream=None, keys_only=False):
+        """30-bit Morton keys + index payload of an [n, 3] f32 point tensor.  `keys_only`: no index
+        array is written (for SortPlan.sort_pairs_indexed); the second value returned is None."""
         n = xyz.numel() // 3
         if xyz.dtype != torch.float32:
             raise ValueError("xyz must be float32")
         if keys_out is None:
             keys_out = torch.empty(n, dtype=torch.int32, device=self.device)
-        if idx_out is None:
+        if idx_out is None and not keys_only:
             idx_out = torch.empty(n, dtype=torch.int32, device=self.device)
-        if keys_out.numel() < n or idx_out.numel() < n:
+        if keys_out.numel() < n or (idx_out is not None and idx_out.numel() < n):
             raise ValueError("output tensors are too small")
         c3 = ctypes.c_float * 3
         _lib.check(
             self.lib.mrs_morton_encode30(
                 self._h, _ptr(xyz), n, c3(*[float(v) for v in mn]), c3(*[float(v) for v in mx]),
-                _ptr(keys_out), _ptr(idx_out), _stream(stream),
+                _ptr(keys_out), _ptr(idx_out) if idx_out is not None else None, _stream(stream),
             )
         )
         return keys_out, idx_out
@@ -232,6 +233,18 @@ class SortPlan:
         _lib.check(
             self.lib.mrs_sort_pairs_primed(self._h, n, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
                                            _stream(stream), ctypes.byref(in_b))
+        )
+        return bool(in_b.value)
+
+    def sort_pairs_indexed(self, keys_a, vals_a, keys_b, vals_b, n=None, stream=None):
+        """`mrs_sort_pairs_indexed`: sort_pairs whose input payload is the element index; vals_a is
+        ping-pong space and need not hold anything.  Returns True when the result is in the B tensors."""
+        n = self.n if n is None else n
+        self._check_sizes(n, (keys_a, keys_b), (vals_a, vals_b))
+        in_b = ctypes.c_int(0)
+        _lib.check(
+            self.lib.mrs_sort_pairs_indexed(self._h, n, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
+                                            _stream(stream), ctypes.byref(in_b))
         )
         return bool(in_b.value)
 

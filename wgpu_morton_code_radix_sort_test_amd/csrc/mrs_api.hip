@@ -45,7 +45,6 @@ int launch_encode30_with_histogram(int num_cus, const float* xyz_dev, uint64_t n
                                    uint32_t* keys_dev, uint32_t* idx_dev, uint32_t* ghist, uint32_t begin_bit,
                                    uint32_t end_bit, uint32_t bits, uint32_t num_passes, hipStream_t s);
 // mrs_gather.hip
-int launch_iota(uint32_t* out, uint32_t n, int num_cus, hipStream_t s);
 int launch_gather(const void* in, const uint32_t* index, void* out, uint32_t n, uint32_t record_bytes, int num_cus,
                   hipStream_t s);
 // mrs_small_sort.hip
@@ -257,16 +256,16 @@ static int launch_global_hist(const mrs_plan* p, const GlobalHistArgs& a, hipStr
 }
 
 // `n` != 0: the scan also fills the plan's pass_plan words (which passes need not run).
-static int launch_ghist_scan(const mrs_plan* p, uint32_t num_passes, uint32_t n, hipStream_t s)
+static int launch_ghist_scan(const mrs_plan* p, uint32_t num_passes, uint32_t n, hipStream_t s, uint32_t keep_passes = 0)
 {
     const unsigned threads = p->radix < 64 ? 64 : p->radix;
     uint32_t* pass_plan = n ? p->control->pass_plan : nullptr;
     if (p->radix_bits == 4)
         hipLaunchKernelGGL(global_histogram_scan_kernel<4>, dim3(num_passes), dim3(threads), 0, s, p->control->ghist,
-                           pass_plan, n, num_passes);
+                           pass_plan, n, num_passes, keep_passes);
     else
         hipLaunchKernelGGL(global_histogram_scan_kernel<8>, dim3(num_passes), dim3(threads), 0, s, p->control->ghist,
-                           pass_plan, n, num_passes);
+                           pass_plan, n, num_passes, keep_passes);
     MRS_CHECK_LAUNCH("global_histogram_scan_kernel");
     return MRS_OK;
 }
@@ -640,11 +639,16 @@ static int check_pair_buffers(const mrs_plan* plan, const void* ka, const void* 
     return MRS_OK;
 }
 
-// The launch schedule shared by mrs_sort_pairs, mrs_sort_pairs_primed and mrs_sort_pairs_noalloc.
+// The launch schedule shared by mrs_sort_pairs, mrs_sort_pairs_primed, mrs_sort_pairs_indexed and
+// mrs_sort_pairs_noalloc.
 // `primed`: the plan's control block already holds the digit histograms of exactly these keys.
+// `indexed`: the payload of input element i is i; vals_a is ping-pong space only and is never read
+// before it is written.
 static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b,
-                           hipStream_t s, int* result_in_b, bool primed, const char* who)
+                           hipStream_t s, int* result_in_b, bool primed, const char* who, bool indexed = false)
 {
+    if (indexed && plan->desc.payload_bytes != 4)
+        return fail(MRS_ERR_INVALID_ARGUMENT, "%s: the plan must sort 4-byte payloads (source indices)", who);
     // result side by pass parity, src/main.rs:819-823
     if (result_in_b) *result_in_b = (plan->num_passes % 2u) == 1u;
     plan->primed_keys = nullptr;  // whatever happens below, the histograms of an encoder call are spent
@@ -663,8 +667,10 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
         a.keys_in = keys_a;
         a.vals_in = vals_a;
         a.keys_out = in_b ? keys_b : keys_a;
-        a.vals_out = vals_b;
-        a.vals_final = in_b ? nullptr : vals_a;
+        // made-up indices read nothing, so they can be written where the result belongs
+        a.vals_out = indexed && !in_b ? vals_a : vals_b;
+        a.vals_final = in_b || indexed ? nullptr : vals_a;
+        a.index_payload = indexed;
         a.n = n32;
         a.begin_bit = plan->desc.begin_bit;
         a.end_bit = plan->desc.end_bit;
@@ -700,7 +706,7 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
             if (int rc = launch_global_hist(plan, h, s)) return rc;
             if (int rc = mark(plan, "global_histogram", s)) return rc;
         }
-        if (int rc = launch_ghist_scan(plan, plan->num_passes, skip_passes ? n32 : 0, s)) return rc;
+        if (int rc = launch_ghist_scan(plan, plan->num_passes, skip_passes ? n32 : 0, s, indexed ? 2u : 0u)) return rc;
         if (int rc = mark(plan, "histogram_scan", s)) return rc;
     }
 
@@ -716,6 +722,7 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
         a.shift = pass_shift(plan, pass);
         a.mask = pass_mask(plan, pass);
         a.digit_map = nullptr;
+        a.index_payload = indexed && pass == 0;
         if (plan->desc.algo == MRS_ALGO_THREE_KERNEL) {
             // "Histogram calculation" / prefix sums / "Indexing", src/main.rs:595-664
             if (int rc = launch_block_hist(plan, n32, a.keys_in, num_tiles, pass, plan->hist, s)) return rc;
@@ -770,6 +777,15 @@ extern "C" int mrs_sort_pairs_primed(mrs_plan* plan, uint64_t n, void* keys_a, v
     }
     return sort_pairs_impl(plan, n, keys_a, vals_a, keys_b, vals_b, static_cast<hipStream_t>(stream), result_in_b, true,
                            "mrs_sort_pairs_primed");
+}
+
+extern "C" int mrs_sort_pairs_indexed(mrs_plan* plan, uint64_t n, void* keys_a, uint32_t* vals_a, void* keys_b,
+                                      uint32_t* vals_b, void* stream, int* result_in_b)
+{
+    clear_error();
+    if (int rc = validate_call(plan, n, "mrs_sort_pairs_indexed")) return rc;
+    return sort_pairs_impl(plan, n, keys_a, vals_a, keys_b, vals_b, static_cast<hipStream_t>(stream), result_in_b, false,
+                           "mrs_sort_pairs_indexed", true);
 }
 
 // No counterpart among the plan-based calls allocates less: this one owns no plan at all.  The
@@ -856,7 +872,7 @@ extern "C" int mrs_morton_encode30_for_sort(mrs_plan* plan, const float* xyz_dev
     if (plan->desc.key_words != 1 || plan->desc.algo != MRS_ALGO_ONESWEEP)
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30_for_sort: the plan must be an onesweep plan for 32-bit keys");
     if (n == 0) return MRS_OK;
-    if (!xyz_dev || !mn || !mx || !keys_dev || !idx_dev)
+    if (!xyz_dev || !mn || !mx || !keys_dev)
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30_for_sort: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     plan->primed_keys = nullptr;
@@ -887,8 +903,9 @@ extern "C" int mrs_sort_gather(mrs_plan* plan, uint64_t n, void* keys_a, void* k
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_sort_gather: null buffer");
     if (records_in == records_out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_sort_gather: records_out aliases records_in");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (int rc = launch_iota(index_a, static_cast<uint32_t>(n), plan->ctx->num_cus, s)) return rc;
-    if (int rc = mrs_sort_pairs(plan, n, keys_a, index_a, keys_b, index_b, stream, &in_b)) return rc;
+    // the first pass makes the source indices up: no iota is written, none is read
+    if (int rc = sort_pairs_impl(plan, n, keys_a, index_a, keys_b, index_b, s, &in_b, false, "mrs_sort_gather", true))
+        return rc;
     if (int rc = launch_gather(records_in, in_b ? index_b : index_a, records_out, static_cast<uint32_t>(n), record_bytes,
                                plan->ctx->num_cus, s))
         return rc;

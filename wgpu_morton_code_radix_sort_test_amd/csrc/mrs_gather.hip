@@ -1,28 +1,15 @@
-// Index payload and final gather: instead of dragging a wide record through every digit pass
-// (the reference moves the 16-byte TriangleIndices 8 times, src/shaders/radix_sort_index.wgsl:
-// 281-307), sort (key, source index) pairs and move each record once at the end.
+// Final gather: instead of dragging a wide record through every digit pass (the reference moves
+// the 16-byte TriangleIndices 8 times, src/shaders/radix_sort_index.wgsl:281-307), sort
+// (key, source index) pairs and move each record once at the end.  The source indices are made
+// up by the first digit pass (PassArgs::index_payload); they are never written as an input.
 #include "mrs_internal.h"
 
 namespace mrs {
 
 namespace {
 
-// 64-bit loop indices: n may lie within one grid stride of 2^32, where a 32-bit index would wrap
-// to a value below n and never leave the loop.
-__global__ __launch_bounds__(256) void iota_kernel(uint32_t* __restrict__ out, uint32_t n)
-{
-    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256u * 4u;
-    for (unsigned long long base = (static_cast<unsigned long long>(blockIdx.x) * 256u + threadIdx.x) * 4u; base < n;
-         base += stride) {
-        const uint32_t b = static_cast<uint32_t>(base);
-        if (base + 3 < n) {
-            *reinterpret_cast<uint4*>(out + base) = make_uint4(b, b + 1, b + 2, b + 3);
-        } else {
-            for (unsigned long long i = base; i < n; ++i) out[i] = static_cast<uint32_t>(i);
-        }
-    }
-}
-
+// 64-bit loop indices throughout: n may lie within one grid stride of 2^32, where a 32-bit index
+// would wrap to a value below n and never leave the loop.
 // out[j] = in[index[j]], records of sizeof(T) bytes
 template <typename T>
 __global__ __launch_bounds__(256) void gather_kernel(const T* __restrict__ in, const uint32_t* __restrict__ index,
@@ -56,13 +43,6 @@ int grid_for(uint64_t items, int num_cus)
 }
 
 }  // namespace
-
-int launch_iota(uint32_t* out, uint32_t n, int num_cus, hipStream_t s)
-{
-    hipLaunchKernelGGL(iota_kernel, dim3(grid_for((n + 3) / 4, num_cus)), dim3(256), 0, s, out, n);
-    MRS_CHECK_LAUNCH("iota_kernel");
-    return MRS_OK;
-}
 
 int launch_gather(const void* in, const uint32_t* index, void* out, uint32_t n, uint32_t record_bytes, int num_cus,
                   hipStream_t s)

@@ -73,6 +73,9 @@ struct PassArgs {
     // exchange the roles of the two buffer pairs.
     const uint32_t* pass_plan;
     uint32_t atomic_rank;        // host side only: rank with returning LDS atomics (kRankAtomic)
+    // 4-byte payloads: the payload of input element i is i itself (the first pass of a sort of
+    // (key, source index) pairs); vals_in is not read
+    uint32_t index_payload;
 #ifdef MRS_STAMPS
     unsigned long long* stamps;  // diagnostic builds only: [num_tiles][8] phase clocks
 #endif
@@ -98,6 +101,7 @@ struct SmallSortArgs {
     uint32_t begin_bit, end_bit;
     uint32_t num_passes;
     uint32_t payload_bytes;  // 0, 4 or 16
+    uint32_t index_payload;  // 4-byte payloads: the payload of input element i is i; vals_in is not read
 };
 
 struct KernelConfig {

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kEncode30Threads) void morton_encode30_kernel(
         const u32x4 kv = {k[0], k[1], k[2], k[3]};
         const u32x4 iv = {i0, i0 + 1, i0 + 2, i0 + 3};
         __builtin_nontemporal_store(kv, reinterpret_cast<u32x4*>(keys + first));
-        __builtin_nontemporal_store(iv, reinterpret_cast<u32x4*>(idx + first));
+        if (idx) __builtin_nontemporal_store(iv, reinterpret_cast<u32x4*>(idx + first));
         if constexpr (HIST) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) count(k[q]);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kEncode30Threads) void morton_encode30_kernel(
             for (int q = 0; q < 4; ++q)
                 if (first + q < n) {
                     keys[first + q] = k[q];
-                    idx[first + q] = static_cast<uint32_t>(first + q);
+                    if (idx) idx[first + q] = static_cast<uint32_t>(first + q);
                     if constexpr (HIST) count(k[q]);
                 }
         }
@@ -307,8 +307,7 @@ extern "C" int mrs_morton_encode30(mrs_context* ctx, const float* xyz_dev, uint6
     if (!ctx) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30: null context");
     if (n == 0) return MRS_OK;
     if (n > 0xFFFFFFFFull) return fail(MRS_ERR_UNSUPPORTED, "mrs_morton_encode30: n must fit in 32 bits");
-    if (!xyz_dev || !mn || !mx || !keys_dev || !idx_dev)
-        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30: null pointer");
+    if (!xyz_dev || !mn || !mx || !keys_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30: null pointer");
     if ((reinterpret_cast<uintptr_t>(xyz_dev) | reinterpret_cast<uintptr_t>(keys_dev) |
          reinterpret_cast<uintptr_t>(idx_dev)) & 15u)
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30: buffers must be 16-byte aligned");

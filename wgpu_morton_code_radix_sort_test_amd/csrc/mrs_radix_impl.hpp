@@ -300,8 +300,13 @@ __global__ __launch_bounds__(1024) void global_histogram_banked_kernel(const Glo
 // "every word is 0 or n" gives the same answer on counts, on their exclusive scan and on any
 // mixture of the two: with one occupied bin both are 0 or n everywhere, and at the second
 // occupied bin of any other histogram the count and the scan both lie strictly between 0 and n.
+//
+// `keep_passes`: the first that many passes run whatever their digits are.  A sort that makes up
+// its payload in pass 0 (PassArgs::index_payload) passes 2: pass 0 has to run for the payload to
+// exist at all, and pass 1 with it for the count of passes left out to stay even.
 template <int BITS>
-__global__ void global_histogram_scan_kernel(uint32_t* ghist, uint32_t* pass_plan, uint32_t n, uint32_t num_passes)
+__global__ void global_histogram_scan_kernel(uint32_t* ghist, uint32_t* pass_plan, uint32_t n, uint32_t num_passes,
+                                             uint32_t keep_passes)
 {
     constexpr int RADIX = 1 << BITS;
     __shared__ uint32_t s[RADIX];
@@ -310,7 +315,7 @@ __global__ void global_histogram_scan_kernel(uint32_t* ghist, uint32_t* pass_pla
     const int t = threadIdx.x;
     const uint32_t own = t < RADIX ? h[t] : 0;
     if (t < RADIX) s[t] = own;
-    if (t < kMaxPasses) s_spread[t] = 0;
+    if (t < kMaxPasses) s_spread[t] = static_cast<uint32_t>(t) < keep_passes ? 1u : 0u;
     __syncthreads();
     if (pass_plan && t < RADIX) {
         for (uint32_t q = 0; q < num_passes; ++q) {

@@ -565,10 +565,22 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     ValT val[KPT];
     if constexpr (HAS_VAL) {
         if (!(kAblate & 4)) {
-            const ValT* __restrict__ vals_in = static_cast<const ValT*>(a.vals_in) + tile_base + my_first;
+            bool fetched = false;
+            if constexpr (std::is_same<ValT, uint32_t>::value) {
+                // a sort of (key, source index) pairs: the first pass makes the indices up
+                if (a.index_payload) {  // uniform
+                    const uint32_t first_index = static_cast<uint32_t>(tile_base) + my_first;
 #pragma unroll
-            for (int i = 0; i < KPT; ++i)
-                if (FULL || my_first + i * 64 < tile_valid) val[i] = policy_load(vals_in + i * 64);
+                    for (int i = 0; i < KPT; ++i) val[i] = first_index + i * 64;
+                    fetched = true;
+                }
+            }
+            if (!fetched) {
+                const ValT* __restrict__ vals_in = static_cast<const ValT*>(a.vals_in) + tile_base + my_first;
+#pragma unroll
+                for (int i = 0; i < KPT; ++i)
+                    if (FULL || my_first + i * 64 < tile_valid) val[i] = policy_load(vals_in + i * 64);
+            }
         }
     }
 

@@ -118,7 +118,11 @@ __global__ __launch_bounds__(kSmallThreads) void small_sort_kernel(const SmallSo
     if (a.payload_bytes == 4) {
         const uint32_t* __restrict__ vin = static_cast<const uint32_t*>(a.vals_in);
         uint32_t* __restrict__ vout = static_cast<uint32_t*>(a.vals_out);
-        for (uint32_t j = tid; j < n; j += kSmallThreads) vout[j] = vin[s_src[cur][j]];
+        if (a.index_payload) {
+            for (uint32_t j = tid; j < n; j += kSmallThreads) vout[j] = s_src[cur][j];
+        } else {
+            for (uint32_t j = tid; j < n; j += kSmallThreads) vout[j] = vin[s_src[cur][j]];
+        }
     } else if (a.payload_bytes == 16) {
         const uint4* __restrict__ vin = static_cast<const uint4*>(a.vals_in);
         uint4* __restrict__ vout = static_cast<uint4*>(a.vals_out);
