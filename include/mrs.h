@@ -184,7 +184,13 @@ int mrs_morton_encode30(mrs_context* ctx, const float* xyz_dev, uint64_t n,
  * kernels' 16-byte loads run in gfx950's unaligned access mode.  MRS_ALGO_ONESWEEP plans for 64-bit keys
  * leave out, on the device, passes whose digit is the same for every key (the
  * constant high bytes of a short code); they are left out in pairs, so the
- * result side stays the one reported here. */
+ * result side stays the one reported here.
+ * The call only enqueues work (one clearing kernel, the histogram, its scan, the
+ * passes), so it may be recorded by a stream capture and replayed as a HIP graph
+ * on new buffer contents; the same holds for mrs_sort_pairs_indexed,
+ * mrs_sort_pairs_noalloc and mrs_sort_gather.  Replays of one plan must not
+ * overlap each other, and with die-aware tickets (mrs_context_set_attribute)
+ * not another sort of the device either. */
 int mrs_sort_pairs(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a,
                    void* keys_b, void* vals_b, void* stream, int* result_in_b);
 

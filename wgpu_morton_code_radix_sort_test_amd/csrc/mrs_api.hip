@@ -29,6 +29,39 @@ int fail(int code, const char* fmt, ...)
 
 void clear_error() { g_last_error.clear(); }
 
+// Zeroes device memory on a stream with a kernel of the library, not with the runtime's
+// asynchronous memset: the memset node that a stream capture makes of the latter was seen to
+// leave the memory untouched when the captured graph is replayed by the HIP runtime a PyTorch
+// process carries (the sort's ticket counters then keep their old values and every workgroup of
+// the passes returns at once), while a kernel node replays like the kernels around it.
+__global__ __launch_bounds__(256) void clear_kernel(uint32_t* __restrict__ p, size_t words)
+{
+    const size_t stride = static_cast<size_t>(gridDim.x) * 256u;
+    const size_t tid = static_cast<size_t>(blockIdx.x) * 256u + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+        uint4* v = reinterpret_cast<uint4*>(p);
+        const size_t vecs = words / 4;
+        for (size_t i = tid; i < vecs; i += stride) v[i] = make_uint4(0, 0, 0, 0);
+        for (size_t i = vecs * 4 + tid; i < words; i += stride) p[i] = 0;
+    } else {
+        for (size_t i = tid; i < words; i += stride) p[i] = 0;
+    }
+}
+
+int clear_async(void* p, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return MRS_OK;
+    if ((reinterpret_cast<uintptr_t>(p) & 3u) || (bytes & 3u))
+        return fail(MRS_ERR_INVALID_ARGUMENT, "clear: address and size must be multiples of 4");
+    const size_t words = bytes / 4;
+    size_t blocks = (words / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(clear_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, static_cast<uint32_t*>(p), words);
+    MRS_CHECK_LAUNCH("clear_kernel");
+    return MRS_OK;
+}
+
 // per-key-type entry points (mrs_radix_u32.hip / mrs_radix_u64.hip)
 int launch_pass_u32(int mode, int bits, int threads, int kpt, int payload_bytes, const PassArgs& a, hipStream_t s);
 int launch_pass_u64(int mode, int bits, int threads, int kpt, int payload_bytes, const PassArgs& a, hipStream_t s);
@@ -171,7 +204,7 @@ static uint32_t xcd_block_tiles(const mrs_context* ctx)
 {
     static const int env = std::getenv("MRS_XCD_BLOCK") ? std::atoi(std::getenv("MRS_XCD_BLOCK")) : -1;
     if (!ctx->die_aware_tickets) return 0;
-    return env >= 0 ? static_cast<uint32_t>(env) : 8u;
+    return env >= 0 ? static_cast<uint32_t>(env > 64 ? 64 : env) : 8u;  // larger blocks only make the dies wait
 }
 
 // Ticket block size for the chained-scan passes of one call on stream `s`: the context's, unless
@@ -691,7 +724,7 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
         const size_t zero = kControlBytes + align_up(region * plan->num_passes, 256);
         // a primed plan keeps its histograms: only the ticket counters and the status words are cleared
         const size_t keep = primed ? offsetof(OnesweepControl, tile_counter) : 0;
-        MRS_HIP_TRY(hipMemsetAsync(plan->zero_begin + keep, 0, zero - keep, s));
+        if (int rc = clear_async(plan->zero_begin + keep, zero - keep, s)) return rc;
         if (int rc = mark(plan, "memset", s)) return rc;
         GlobalHistArgs h{};
         h.keys = keys_a;
@@ -876,7 +909,7 @@ extern "C" int mrs_morton_encode30_for_sort(mrs_plan* plan, const float* xyz_dev
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30_for_sort: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     plan->primed_keys = nullptr;
-    MRS_HIP_TRY(hipMemsetAsync(plan->control->ghist, 0, sizeof(plan->control->ghist), s));
+    if (int rc = clear_async(plan->control->ghist, sizeof(plan->control->ghist), s)) return rc;
     if (int rc = launch_encode30_with_histogram(plan->ctx->num_cus, xyz_dev, n, mn, mx, keys_dev, idx_dev,
                                                 plan->control->ghist, plan->desc.begin_bit, plan->desc.end_bit,
                                                 plan->radix_bits, plan->num_passes, s))
@@ -972,7 +1005,7 @@ extern "C" int mrs_bucket_histogram(mrs_context* ctx, const void* keys_dev, uint
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_bucket_histogram: need 1 <= bits <= 12 inside the key");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t bins = 1u << bits;
-    MRS_HIP_TRY(hipMemsetAsync(counts_dev, 0, bins * sizeof(uint64_t), s));
+    if (int rc = clear_async(counts_dev, bins * sizeof(uint64_t), s)) return rc;
     if (n == 0) return MRS_OK;
     if (!keys_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_bucket_histogram: null keys");
     const uint64_t vec = key_words == 1 ? 4 : 2;
@@ -1011,7 +1044,7 @@ int partition_internal(mrs_plan* plan, uint64_t n, const void* keys_in, const vo
     const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
     const size_t zero =
         kControlBytes + align_up(static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes, 256);
-    MRS_HIP_TRY(hipMemsetAsync(plan->zero_begin, 0, zero, s));
+    if (int rc = clear_async(plan->zero_begin, zero, s)) return rc;
     if (class_starts_dev) {
         MRS_HIP_TRY(hipMemcpyAsync(plan->control->ghist, class_starts_dev, plan->radix * sizeof(uint32_t),
                                    hipMemcpyDeviceToDevice, s));
@@ -1090,7 +1123,8 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
     if (!map_dev) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_partition: null map");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) {
-        if (part_counts_dev) MRS_HIP_TRY(hipMemsetAsync(part_counts_dev, 0, 16 * sizeof(uint32_t), s));
+        if (part_counts_dev)
+            if (int rc = clear_async(part_counts_dev, 16 * sizeof(uint32_t), s)) return rc;
         return MRS_OK;
     }
     if (int rc = check_pair_buffers(plan, keys_in, vals_in, keys_out, vals_out, "mrs_partition")) return rc;
@@ -1099,7 +1133,7 @@ extern "C" int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, co
         return rc;
     if (part_counts_dev) {
         const size_t have = (plan->radix < 16 ? plan->radix : 16) * sizeof(uint32_t);
-        MRS_HIP_TRY(hipMemsetAsync(part_counts_dev, 0, 16 * sizeof(uint32_t), s));
+        if (int rc = clear_async(part_counts_dev, 16 * sizeof(uint32_t), s)) return rc;
         MRS_HIP_TRY(hipMemcpyAsync(part_counts_dev, plan->control->ghist, have, hipMemcpyDeviceToDevice, s));
     }
     return partition_pass(plan, n, keys_in, vals_in, keys_out, vals_out, shift, bits, map_dev, nullptr, 0, 0, true, s);

@@ -695,7 +695,7 @@ extern "C" int mrs_dist_sort_pairs(mrs_dist* dist, uint64_t n_local, const void*
         if (first) {
             if (int rc = mrs_bucket_histogram(d->ctx, keys_in, n_local, kw, shift, bits, d->hist_local, s)) return rc;
         } else {
-            MRS_HIP_TRY(hipMemsetAsync(d->hist_local, 0, count * sizeof(uint64_t), s));
+            if (int rc = clear_async(d->hist_local, count * sizeof(uint64_t), s)) return rc;
             PrefixHistArgs a{};
             a.keys = keys_in;
             a.n = n_local;

@@ -15,6 +15,8 @@ namespace mrs {
 // Records the calling thread's error message and returns `code`.
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 void clear_error();
+// Zeroes `bytes` of device memory (address and size multiples of 4) behind the work already on `s`.
+int clear_async(void* p, size_t bytes, hipStream_t s);
 
 #define MRS_HIP_TRY(expr)                                                              \
     do {                                                                               \
