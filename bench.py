@@ -109,7 +109,8 @@ def cpu_baseline(sample_keys, sample_idx, whole):
 
 
 def c4_leg(ctx, log2n=30, sorts=3):
-    """The 2^30-pair configuration: 64-bit tile status words and offsets; HIP events of the library
+    """The 2^30-pair configuration (and, with log2n=31, the whole 2^31-pair job of the 8-GPU
+    configuration on one GPU): 64-bit tile status words and offsets; HIP events of the library
     around every launch.  Returns None when the device is short of memory."""
     n = 1 << log2n
     free_b, _ = torch.cuda.mem_get_info()
@@ -143,7 +144,7 @@ def c4_leg(ctx, log2n=30, sorts=3):
         "per_pass_ms": [round(float(x), 4) for x in passes],
         "pass_frac_16B": PASS_BYTES_PER_PAIR * n / (float(np.mean(passes)) * 1e-3) / HBM_PEAK_BYTES_PER_S,
         "tile_status_words": "64-bit",
-        "timing": "HIP events recorded by the library around every launch of 3 sorts after 1 warm-up",
+        "timing": f"HIP events recorded by the library around every launch of {sorts} sorts after 1 warm-up",
         "verified": bool(ok),
     }
 
@@ -383,6 +384,7 @@ def main():
         cpu, _, _ = cpu_baseline(sample_k, sample_i, m == n)
 
     c4 = None
+    c5_one_gpu = None
     if rank == 0 and not distributed and not args.no_c4 and algo == mrs.ALGO_ONESWEEP and args.log2n == 28:
         # free the pool first: the 2^30 leg wants about 45 GiB
         del inputs, kb, vb, out
@@ -393,6 +395,12 @@ def main():
             c4 = c4_leg(ctx)
         except Exception as exc:  # an extra: the headline line stands without it
             c4 = {"error": str(exc)}
+        # the whole 8-GPU job (2^31 pairs) on this one GPU: the one-GPU point of a curve over 2^31 keys
+        torch.cuda.empty_cache()
+        try:
+            c5_one_gpu = c4_leg(ctx, log2n=31, sorts=2)
+        except Exception as exc:
+            c5_one_gpu = {"error": str(exc)}
 
     if rank == 0:
         line = {
@@ -426,6 +434,8 @@ def main():
         line.update(extra)
         if c4 is not None:
             line["c4"] = c4
+        if c5_one_gpu is not None:
+            line["c5_one_gpu"] = c5_one_gpu
         line.update(breakdown)
         print(json.dumps(line))
     if distributed:

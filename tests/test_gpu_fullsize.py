@@ -33,9 +33,11 @@ def check_sorted_pairs(keys_out, idx_out, keys_in):
     assert int(kin.sum()) == int(k.sum())
 
 
-@pytest.mark.parametrize("log2n,algo_name,bits", [(28, "onesweep", 8), (28, "three_kernel", 8), (30, "onesweep", 8)])
+@pytest.mark.parametrize("log2n,algo_name,bits", [(28, "onesweep", 8), (28, "three_kernel", 8), (30, "onesweep", 8),
+                                                  (31, "onesweep", 8)])
 def test_full_size_sort_properties(ctx, mrs, log2n, algo_name, bits):
-    """The metric size and the largest single-GPU size: 2^28 and 2^30 (Morton key, index) pairs."""
+    """The metric size, the largest single-GPU configuration and the whole 8-GPU job on one GPU
+    (the one-GPU point of the scaling curve): 2^28, 2^30 and 2^31 (Morton key, index) pairs."""
     n = 1 << log2n
     free_b, _ = torch.cuda.mem_get_info()
     if free_b < 60 * n:
@@ -56,6 +58,13 @@ def test_full_size_sort_properties(ctx, mrs, log2n, algo_name, bits):
     k2, v2 = keys.clone(), idx.clone()
     plan.sort_pairs(k2, v2, kb, vb)
     plan.check()
+    assert bool((k2 == keys).all()) and bool((v2 == idx).all())
+    # the sort that makes the indices up gives the same pairs
+    k2.copy_(keys_in)
+    v2.fill_(-1)
+    in_b = plan.sort_pairs_indexed(k2, v2, kb, vb)
+    plan.check()
+    assert not in_b
     assert bool((k2 == keys).all()) and bool((v2 == idx).all())
     plan.close()
 
