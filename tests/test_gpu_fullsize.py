@@ -164,16 +164,18 @@ def test_sharded_sort_one_rccl_rank_full_size(ctx, mrs, dist_name):
     comm.close()
 
 
-@pytest.mark.parametrize("dist_name", ["morton30", "all_equal", "one_hot_bucket"])
-def test_sharded_sort_two_ranks_on_one_gpu_large(ctx, mrs, dist_name):
-    """Two in-process ranks of 2^26 pairs each share the GPU: the partition pass, the splitter's
-    deeper levels (skewed inputs) and the exchange layout at a size where every kernel runs many
-    tiles.  Checked through the properties of a global stable sort."""
+@pytest.mark.parametrize("world,log2n,dist_name", [(2, 26, "morton30"), (2, 26, "all_equal"), (2, 26, "one_hot_bucket"),
+                                                   (8, 24, "morton30"), (8, 24, "one_hot_bucket")])
+def test_sharded_sort_ranks_on_one_gpu_large(ctx, mrs, world, log2n, dist_name):
+    """In-process ranks share the GPU, two of 2^26 pairs each and eight of 2^24 (the rank count of
+    the 8-GPU configuration: 16 destination pieces in the partition pass): the partition pass, the
+    splitter's deeper levels (skewed inputs) and the exchange layout at sizes where every kernel
+    runs many tiles.  Checked through the properties of a global stable sort."""
     import threading
 
     from wgpu_morton_code_radix_sort_test_amd.dist import Communicator, DistributedSorter
 
-    world, n = 2, 1 << 26
+    n = 1 << log2n
     comms = Communicator.local(world)
     outs, ins, errors = [None] * world, [None] * world, []
 
@@ -220,7 +222,7 @@ def test_sharded_sort_two_ranks_on_one_gpu_large(ctx, mrs, dist_name):
     for o in outs:
         assert abs(o[0].numel() - n) <= 2 * tol + 1
     if dist_name == "all_equal":
-        # two ranks, each receiving its share in two pieces: three cuts, all inside the run of equal keys
-        assert all(o[2].last_exact_cuts == 3 for o in outs) and outs[0][0].numel() == n
+        # each rank receives its share in two pieces: 2 * world - 1 cuts, all inside the run of equal keys
+        assert all(o[2].last_exact_cuts == 2 * world - 1 for o in outs) and outs[0][0].numel() == n
     if dist_name == "one_hot_bucket":
         assert all(o[2].last_levels >= 2 for o in outs)
