@@ -439,6 +439,10 @@ def main():
         line.update(breakdown)
         print(json.dumps(line))
     if distributed:
+        # every rank is past its last collective before any communicator goes away
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         sorter.close()
         comm.close()
         if dist.is_initialized():
