@@ -17,8 +17,9 @@ def to_u32(t):
 
 
 def gpu_sort(ctx, mrs, keys, vals, n, key_words, payload_words, bits, begin, end, algo, tile_items=0,
-             capacity=None):
-    """Runs mrs_sort_pairs; returns (keys_out, vals_out, result_in_b) as numpy u32 arrays."""
+             capacity=None, indexed=False):
+    """Runs mrs_sort_pairs (or, with `indexed`, mrs_sort_pairs_indexed on a payload buffer filled
+    with junk); returns (keys_out, vals_out, result_in_b) as numpy u32 arrays."""
     dev = ctx.device
     plan = mrs.SortPlan(ctx, capacity or max(n, 1), key_words=key_words, payload_bytes=4 * payload_words,
                         digit_bits=bits, begin_bit=begin, end_bit=end, algo=algo, tile_items=tile_items)
@@ -28,7 +29,11 @@ def gpu_sort(ctx, mrs, keys, vals, n, key_words, payload_words, bits, begin, end
     if payload_words:
         va = to_dev(vals, dev) if n else torch.zeros(payload_words, dtype=torch.int32, device=dev)
         vb = torch.full_like(va, -1)
-    in_b = plan.sort_pairs(ka, va, kb, vb, n=n)
+    if indexed:
+        va.fill_(0x3C3C3C3C)
+        in_b = plan.sort_pairs_indexed(ka, va, kb, vb, n=n)
+    else:
+        in_b = plan.sort_pairs(ka, va, kb, vb, n=n)
     plan.check()
     ko = to_u32(kb if in_b else ka)[: n * key_words]
     vo = to_u32(vb if in_b else va)[: n * payload_words] if payload_words else None

@@ -157,6 +157,38 @@ def test_local_ranks_match_one_stable_sort(oracle, mrs, world, key_words, end_bi
         assert all(i.last_levels == 1 and i.last_exact_cuts == 0 for i in infos)
 
 
+def test_local_ranks_fuzz(oracle, mrs):
+    """Seeded random shapes of the sharded sort: rank count, slice sizes (empty and tiny slices
+    included), key width and live bits, distribution, tolerance and pieces per rank drawn together.
+    MRS_DIST_FUZZ_CASES / MRS_DIST_FUZZ_SEED widen a run."""
+    import os
+
+    rng = np.random.default_rng(int(os.environ.get("MRS_DIST_FUZZ_SEED", "5")))
+    dists = ["random", "morton30", "all_equal", "hot_bucket", "few_values", "sorted", "few_distinct", "one_hot_digit"]
+    for case in range(int(os.environ.get("MRS_DIST_FUZZ_CASES", "10"))):
+        world = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 11, 16]))
+        key_words = int(rng.choice([1, 1, 2]))
+        dist = dists[int(rng.integers(len(dists)))]
+        end_bit = 30 if dist == "morton30" else int(rng.integers(32 * (key_words - 1) + 13, 32 * key_words + 1))
+        if dist == "morton30":
+            key_words = 1
+        sizes = [int(rng.choice([0, 1, int(rng.integers(2, 300)), int(rng.integers(300, 6000)), int(rng.integers(6000, 60000))],
+                                p=[0.08, 0.04, 0.13, 0.25, 0.5])) for _ in range(world)]
+        chunks = int(rng.choice([0, 1, 2])) if 2 * world <= 16 else int(rng.choice([0, 1]))
+        tolerance = [None, None, 1, int(rng.integers(1, 500))][int(rng.integers(4))]
+        host_keys = [rank_keys(oracle, n, key_words, dist, seed=1000 * case + r, end_bit=end_bit) for r, n in enumerate(sizes)]
+        tol = max(max(sizes), 1) // 256 if tolerance is None else tolerance
+        what = (case, world, key_words, end_bit, dist, sizes, chunks, tolerance)
+        try:
+            results, _ = run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, 0 if tolerance is None else tolerance,
+                                   chunks=chunks)
+            check_against_oracle(oracle, results, host_keys, sizes, key_words, end_bit, max(tol, 1))
+        except AssertionError as exc:
+            raise AssertionError(f"{what}: {exc}") from exc
+        except Exception as exc:  # noqa: BLE001
+            raise RuntimeError(f"{what}: {exc}") from exc
+
+
 def test_repeated_calls_and_shrinking_input(oracle, mrs):
     """The same handles sort twice in a row, the second time a smaller input (stale status words,
     tables and counts of the first call must not leak into the second)."""

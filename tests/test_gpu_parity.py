@@ -273,8 +273,9 @@ def test_small_sort_bit_ranges(ctx, oracle, mrs):
 def test_sort_fuzz(ctx, oracle, mrs):
     """Seeded random plans: size, element type, digit width, bit range, tile size, algorithm and
     key distribution drawn together; every result must equal the checker's stable sort."""
-    rng = np.random.RandomState(20240611)
-    mask_rng = np.random.RandomState(77)
+    seed = int(os.environ.get("MRS_FUZZ_SEED", "20240611"))
+    rng = np.random.RandomState(seed)
+    mask_rng = np.random.RandomState(seed % 1000 + 77)
     tiles_small = {(1, 0): [0, 256, 1024, 4096, 8192, 16384, 32768], (1, 1): [0, 256, 1024, 4096, 8192, 16384, 32768],
                    (2, 0): [0, 256, 1024, 4096, 16384], (2, 1): [0, 256, 1024, 4096, 16384],
                    (2, 4): [0, 256, 1024, 4096, 8192], (1, 4): [0, 256, 1024, 4096, 8192]}
@@ -300,9 +301,14 @@ def test_sort_fuzz(ctx, oracle, mrs):
                 k2[:, w] = (k2[:, w] & np.uint32(live[w])) | np.uint32(0x5A5A5A5A & ~live[w] & 0xFFFFFFFF)
             keys = k2.reshape(-1)
         vals = make_vals(oracle, n, payload_words)
-        ko, vo, in_b = gpu_sort(ctx, mrs, keys, vals, n, key_words, payload_words, bits, begin, end, algo, tile_items=tile)
+        # every third case with a 4-byte payload sorts (key, source index) with the indices made up on the device
+        indexed = payload_words == 1 and case % 3 == 0
+        if indexed:
+            vals = np.arange(n, dtype=np.uint32)
+        ko, vo, in_b = gpu_sort(ctx, mrs, keys, vals, n, key_words, payload_words, bits, begin, end, algo, tile_items=tile,
+                                indexed=indexed)
         rk, rv = oracle.stable_sort_pairs(keys, vals, n, key_words, payload_words, begin, end)
-        what = (case, key_words, payload_words, bits, begin, end, tile, n, dist, algo, live)
+        what = (case, key_words, payload_words, bits, begin, end, tile, n, dist, algo, live, indexed)
         assert in_b == (((end - begin + bits - 1) // bits) % 2 == 1), what
         assert np.array_equal(ko, rk), what
         if payload_words:
