@@ -47,6 +47,17 @@ extern "C" {
 /* pass algorithm */
 #define MRS_ALGO_THREE_KERNEL 0 /* histogram -> prefix sum -> scatter, as src/main.rs:594-665 */
 #define MRS_ALGO_ONESWEEP 1     /* one histogram kernel + one chained-scan kernel per digit   */
+#define MRS_ALGO_HYBRID 2       /* (u32 key, 4-byte payload) pairs on 25..32 key bits, n < 2^30:
+                                   three moves of every pair instead of the four of
+                                   src/main.rs:594 -- two chained-scan scatters by the top two
+                                   digits (the second one bucket by bucket), then every one of
+                                   the 65536 sub-buckets sorted inside a workgroup's LDS and
+                                   written back sequentially.  A 16-bit histogram taken first
+                                   lets the DEVICE fall back to the four MRS_ALGO_ONESWEEP
+                                   passes when a sub-bucket would not fit (clustered or equal
+                                   keys, n above about 2^28.8); the result, its side and its
+                                   stability are those of MRS_ALGO_ONESWEEP either way.  Costs
+                                   about 34 MiB more temporary memory                           */
 
 /* byte sizes of the reference buffer elements */
 #define MRS_MORTON_UNIFORMS_BYTES 51248 /* MortonCodeConstants, morton_code.wgsl:19-26 */

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--digit-bits", type=int, default=8)
     ap.add_argument("--algo", default="onesweep")
     ap.add_argument("--key-words", type=int, default=1)
+    ap.add_argument("--end-bit", type=int, default=0, help="one past the last key bit sorted on (0: the whole key)")
     ap.add_argument("--payload-bytes", type=int, default=4)
     ap.add_argument("--dist", default="morton30", choices=["morton30", "random", "sorted", "equal"])
     ap.add_argument("--hi-mask", type=lambda v: int(v, 0), default=0xFFFFFFFF,
@@ -33,9 +34,10 @@ def main():
     args = ap.parse_args()
     ctx = mrs.Context(0)
     n = args.n or (1 << args.log2n)
-    algo = mrs.ALGO_ONESWEEP if args.algo == "onesweep" else mrs.ALGO_THREE_KERNEL
+    algo = {"onesweep": mrs.ALGO_ONESWEEP, "hybrid": mrs.ALGO_HYBRID}.get(args.algo, mrs.ALGO_THREE_KERNEL)
     plan = mrs.SortPlan(ctx, n, key_words=args.key_words, payload_bytes=4 if args.gather else args.payload_bytes,
-                        digit_bits=args.digit_bits, algo=algo, tile_items=args.tile_items)
+                        digit_bits=args.digit_bits, algo=algo, tile_items=args.tile_items,
+                        end_bit=args.end_bit or None)
     plan.set_timing(True)
     kw, pw = args.key_words, args.payload_bytes // 4
     kb = torch.empty(n * kw, dtype=torch.int32, device=ctx.device)

@@ -6,6 +6,7 @@ multi-GPU driver.  torch supplies device memory, streams and torch.distributed.
 """
 from ._lib import MrsError, load_library, library_path  # noqa: F401
 from .api import (  # noqa: F401
+    ALGO_HYBRID,
     ALGO_ONESWEEP,
     ALGO_THREE_KERNEL,
     Context,

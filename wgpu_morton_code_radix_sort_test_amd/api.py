@@ -14,6 +14,7 @@ from . import _lib
 
 ALGO_THREE_KERNEL = 0
 ALGO_ONESWEEP = 1
+ALGO_HYBRID = 2
 
 MORTON_UNIFORMS_BYTES = 51248
 VERTEX_STRIDE = 48

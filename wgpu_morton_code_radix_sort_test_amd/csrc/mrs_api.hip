@@ -9,6 +9,7 @@
 #include <mutex>
 #include <string>
 
+#include "mrs_hybrid.hpp"
 #include "mrs_internal.h"
 #include "mrs_radix_impl.hpp"
 
@@ -496,8 +497,27 @@ extern "C" int mrs_context_destroy(mrs_context* ctx)
 static int fill_plan(mrs_plan* p, mrs_context* ctx, const mrs_plan_desc* d, const char* who)
 {
     if (d->n == 0 || d->n >= 0xFFFFFFFFull) return fail(MRS_ERR_INVALID_ARGUMENT, "%s: n must satisfy 0 < n < 2^32 - 1", who);
-    if (d->algo != MRS_ALGO_THREE_KERNEL && d->algo != MRS_ALGO_ONESWEEP)
+    if (d->algo != MRS_ALGO_THREE_KERNEL && d->algo != MRS_ALGO_ONESWEEP && d->algo != MRS_ALGO_HYBRID)
         return fail(MRS_ERR_INVALID_ARGUMENT, "%s: unknown algo %d", who, d->algo);
+    mrs_plan_desc resolved = *d;
+    bool hybrid = false;
+    if (d->algo == MRS_ALGO_HYBRID) {
+        // The schedule of mrs_hybrid.hpp exists for one element shape; it is an MRS_ALGO_ONESWEEP plan
+        // with more temporary memory and a device-side choice between two schedules.
+        const int width = d->end_bit - d->begin_bit;
+        if (d->key_words != 1 || d->payload_bytes != 4 || d->digit_bits != 8 || width < 25 || width > 32 ||
+            d->n >= (1ull << 30) || (d->tile_items != 0 && d->tile_items != 4096 && d->tile_items != 32768))
+            return fail(MRS_ERR_UNSUPPORTED,
+                        "%s: MRS_ALGO_HYBRID sorts (u32 key, 4-byte payload) pairs on 25 to 32 key bits with 8-bit digits, "
+                        "n < 2^30, tile_items 0, 4096 or 32768",
+                        who);
+        resolved.algo = MRS_ALGO_ONESWEEP;
+        if (resolved.tile_items == 0) resolved.tile_items = d->n >= (1ull << 20) ? 32768 : 4096;
+        // ranking by returning LDS atomics is all the gated kernels are built for; a device that
+        // failed the lane-order check gets the plain chained-scan plan
+        hybrid = ctx->lds_atomics_in_lane_order && !std::getenv("MRS_FORCE_WIDE_STATUS");
+        d = &resolved;
+    }
     KernelConfig cfg;
     if (!config_supported(d->n, d->key_words, d->payload_bytes, d->digit_bits, d->tile_items, d->algo, &cfg))
         return fail(MRS_ERR_UNSUPPORTED, "%s: unsupported shape (key_words %d, payload_bytes %d, digit_bits %d, tile_items %d)",
@@ -508,6 +528,7 @@ static int fill_plan(mrs_plan* p, mrs_context* ctx, const mrs_plan_desc* d, cons
                     d->end_bit, key_bits);
     p->ctx = ctx;
     p->desc = *d;
+    p->hybrid = hybrid;
     p->radix_bits = d->digit_bits;
     p->radix = 1u << d->digit_bits;
     p->num_passes = (d->end_bit - d->begin_bit + d->digit_bits - 1) / d->digit_bits;
@@ -530,11 +551,30 @@ static int fill_plan(mrs_plan* p, mrs_context* ctx, const mrs_plan_desc* d, cons
     return MRS_OK;
 }
 
-// Device bytes a onesweep plan needs: [error flag, 256 B][control block][status words].
+// Status-word bytes one call on `num_tiles` tiles uses (and clears).  The two schedules of a
+// hybrid plan never run in the same call, so they share the space: pass A takes the first pass
+// region, pass B, which has up to 256 tiles more than the array has (every bucket ends in a tile of
+// its own), what follows it.
+static size_t status_bytes(const mrs_plan* p, uint64_t num_tiles)
+{
+    const size_t region = static_cast<size_t>(num_tiles) * p->radix * p->status_word_bytes;
+    size_t bytes = region * p->num_passes;
+    if (p->hybrid) {
+        const size_t ab = region + static_cast<size_t>(num_tiles + kHybBuckets) * p->radix * p->status_word_bytes;
+        if (ab > bytes) bytes = ab;
+    }
+    return align_up(bytes, 256);
+}
+
+// Device bytes a onesweep plan needs: [error flag, 256 B][control block][hybrid plans: header,
+// 256 B][status words][hybrid plans: tables, packed histograms].
 static size_t onesweep_temp_bytes(const mrs_plan* p)
 {
-    return 256 + kControlBytes +
-           align_up(p->histogram_len * p->status_word_bytes * static_cast<size_t>(p->num_passes), 256);
+    size_t bytes = 256 + kControlBytes + status_bytes(p, p->max_tiles);
+    if (p->hybrid)
+        bytes += sizeof(HybridHeader) + hybrid_tables_bytes() +
+                 hybrid_packed_bytes(hybrid_histogram_grid(p->ctx->num_cus, p->desc.n));
+    return bytes;
 }
 
 // Points the plan at `temp`, a zeroed block of onesweep_temp_bytes(p) bytes.  Everything after
@@ -546,6 +586,13 @@ static void bind_onesweep_memory(mrs_plan* p, void* temp)
     p->zero_begin = static_cast<char*>(temp) + 256;
     p->control = reinterpret_cast<OnesweepControl*>(p->zero_begin);
     p->status = p->zero_begin + kControlBytes;
+    if (p->hybrid) {
+        p->hyb_header = reinterpret_cast<HybridHeader*>(p->status);
+        p->status += sizeof(HybridHeader);
+        char* after = p->status + status_bytes(p, p->max_tiles);
+        p->hyb_tables = reinterpret_cast<HybridTables*>(after);
+        p->hyb_packed = reinterpret_cast<uint32_t*>(after + hybrid_tables_bytes());
+    }
 }
 
 extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_plan** out)
@@ -672,6 +719,119 @@ static int check_pair_buffers(const mrs_plan* plan, const void* ka, const void* 
     return MRS_OK;
 }
 
+// Inputs below this size take the plan's ordinary passes: the local sort visits 65536 sub-buckets
+// whatever n is (MRS_HYBRID_MIN_N: test aid, to run the schedule on inputs a checker can follow).
+static uint64_t hybrid_min_n()
+{
+    if (const char* e = std::getenv("MRS_HYBRID_MIN_N")) return std::strtoull(e, nullptr, 10);
+    return 1ull << 22;
+}
+
+// The schedule of an MRS_ALGO_HYBRID plan (mrs_hybrid.hpp): both pass sequences are enqueued and the
+// device runs one of them.
+static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* vals_a, void* keys_b, void* vals_b,
+                             hipStream_t s, bool indexed)
+{
+    const uint32_t num_tiles = (n32 + plan->tile_items - 1) / plan->tile_items;
+    const uint32_t xcd_block = begin_ticketed_call(plan->ctx, s, plan->lineage);
+    const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
+    const size_t zero = static_cast<size_t>(plan->status - plan->zero_begin) + status_bytes(plan, num_tiles);
+    if (int rc = clear_async(plan->zero_begin, zero, s)) return rc;
+    if (int rc = mark(plan, "memset", s)) return rc;
+    const uint32_t begin_bit = plan->desc.begin_bit, end_bit = plan->desc.end_bit;
+    const int hist_grid = hybrid_histogram_grid(plan->ctx->num_cus, n32);
+    if (int rc = hybrid_launch_histogram(static_cast<const uint32_t*>(keys_a), n32, end_bit - 16, hist_grid,
+                                         plan->hyb_packed, plan->hyb_header, s))
+        return rc;
+    if (int rc = mark(plan, "msd_histogram", s)) return rc;
+    // MRS_HYBRID_FORCE_FALLBACK: test aid, the device takes the plan's ordinary passes whatever the keys are
+    const uint32_t force = std::getenv("MRS_HYBRID_FORCE_FALLBACK") ? kHybFallback : 0u;
+    if (int rc = hybrid_launch_scan(plan->hyb_packed, hist_grid, plan->hyb_tables, plan->hyb_header, n32,
+                                    plan->tile_items, force, s))
+        return rc;
+    if (int rc = mark(plan, "msd_scan", s)) return rc;
+    // the other schedule's digit histograms: counted only if the device chose it
+    GlobalHistArgs h{};
+    h.keys = keys_a;
+    h.n = n32;
+    h.begin_bit = begin_bit;
+    h.end_bit = end_bit;
+    h.num_passes = plan->num_passes;
+    h.ghist = plan->control->ghist;
+    h.gate = &plan->hyb_header->mode;
+    h.gate_value = kHybFallback;
+    if (int rc = launch_global_hist(plan, h, s)) return rc;
+    if (int rc = mark(plan, "fallback_histogram", s)) return rc;
+    if (int rc = launch_ghist_scan(plan, plan->num_passes, 0, s)) return rc;
+    if (int rc = mark(plan, "histogram_scan", s)) return rc;
+
+    PassArgs a{};
+    a.n = n32;
+    a.num_tiles = num_tiles;
+    a.mask = 255u;
+    a.wide_status = 0;
+    a.xcd_block = xcd_block;
+    a.error_flag = plan->error_flag;
+    // pass A: a -> b by the top digit
+    a.keys_in = keys_a;
+    a.vals_in = vals_a;
+    a.keys_out = keys_b;
+    a.vals_out = vals_b;
+    a.shift = end_bit - 8;
+    a.digit_base = plan->hyb_tables->bucket_start;
+    a.status = plan->status;
+    a.tile_counter = plan->control->tile_counter[kMaxPasses - 2];
+    a.index_payload = indexed;
+    if (int rc = hybrid_launch_pass(false, false, plan->threads, plan->kpt, a, plan->hyb_header, plan->hyb_tables, kHybRun,
+                                    num_tiles, s))
+        return rc;
+    if (int rc = mark(plan, "msd_pass_a", s)) return rc;
+    // pass B: b -> a by the next digit, bucket by bucket
+    a.keys_in = keys_b;
+    a.vals_in = vals_b;
+    a.keys_out = keys_a;
+    a.vals_out = vals_a;
+    a.shift = end_bit - 16;
+    a.digit_base = nullptr;
+    a.status = plan->status + region;
+    a.tile_counter = plan->control->tile_counter[kMaxPasses - 1];
+    a.index_payload = 0;
+    if (int rc = hybrid_launch_pass(true, false, plan->threads, plan->kpt, a, plan->hyb_header, plan->hyb_tables, kHybRun,
+                                    num_tiles + kHybBuckets, s))
+        return rc;
+    if (int rc = mark(plan, "msd_pass_b", s)) return rc;
+    // the remaining bits, inside LDS, in place
+    const uint32_t low_bits = end_bit - 16 - begin_bit;  // 9..16
+    const uint32_t bits1 = (low_bits + 1) / 2;
+    if (int rc = hybrid_launch_local_sort(static_cast<uint32_t*>(keys_a), static_cast<uint32_t*>(vals_a), plan->hyb_header,
+                                          plan->hyb_tables, begin_bit, bits1, low_bits - bits1,
+                                          hybrid_local_sort_grid(plan->ctx->num_cus), s))
+        return rc;
+    if (int rc = mark(plan, "msd_local_sort", s)) return rc;
+    // the plan's ordinary passes, for inputs the device found unfit: a few workgroups that return
+    // at once otherwise
+    const uint32_t persistent_grid = num_tiles < static_cast<uint32_t>(plan->ctx->num_cus) ? num_tiles : plan->ctx->num_cus;
+    for (uint32_t pass = 0; pass < plan->num_passes; ++pass) {
+        const bool even = (pass % 2u) == 0u;
+        a.keys_in = even ? keys_a : keys_b;
+        a.vals_in = even ? vals_a : vals_b;
+        a.keys_out = even ? keys_b : keys_a;
+        a.vals_out = even ? vals_b : vals_a;
+        a.shift = pass_shift(plan, pass);
+        a.mask = pass_mask(plan, pass);
+        a.digit_base = plan->control->ghist + static_cast<size_t>(pass) * plan->radix;
+        a.status = plan->status + static_cast<size_t>(pass) * region;
+        a.tile_counter = plan->control->tile_counter[pass];
+        a.index_payload = indexed && pass == 0;
+        if (int rc = hybrid_launch_pass(false, true, plan->threads, plan->kpt, a, plan->hyb_header, plan->hyb_tables,
+                                        kHybFallback, persistent_grid, s))
+            return rc;
+        if (int rc = mark(plan, "fallback_pass", s)) return rc;
+    }
+    end_ticketed_call(plan->ctx, s, xcd_block, plan->lineage);
+    return MRS_OK;
+}
+
 // The launch schedule shared by mrs_sort_pairs, mrs_sort_pairs_primed, mrs_sort_pairs_indexed and
 // mrs_sort_pairs_noalloc.
 // `primed`: the plan's control block already holds the digit histograms of exactly these keys.
@@ -712,6 +872,8 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
         if (int rc = launch_small_sort(plan->desc.key_words, plan->radix_bits, a, s)) return rc;
         return mark(plan, "small_sort", s);
     }
+    if (plan->hybrid && !primed && n >= hybrid_min_n())
+        return sort_pairs_hybrid(plan, n32, keys_a, vals_a, keys_b, vals_b, s, indexed);
     // 64-bit keys: passes whose digit is the same for every key are left out on the device
     // (see global_histogram_scan_kernel; MRS_NO_PASS_SKIP=1: A/B aid)
     static const bool no_pass_skip = std::getenv("MRS_NO_PASS_SKIP") != nullptr;
@@ -721,7 +883,7 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
     if (plan->desc.algo == MRS_ALGO_ONESWEEP) {
         xcd_block = begin_ticketed_call(plan->ctx, s, plan->lineage);
         const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
-        const size_t zero = kControlBytes + align_up(region * plan->num_passes, 256);
+        const size_t zero = static_cast<size_t>(plan->status - plan->zero_begin) + align_up(region * plan->num_passes, 256);
         // a primed plan keeps its histograms: only the ticket counters and the status words are cleared
         const size_t keep = primed ? offsetof(OnesweepControl, tile_counter) : 0;
         if (int rc = clear_async(plan->zero_begin + keep, zero - keep, s)) return rc;
@@ -1042,8 +1204,8 @@ int partition_internal(mrs_plan* plan, uint64_t n, const void* keys_in, const vo
     plan->pass_plan_live = false;
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
-    const size_t zero =
-        kControlBytes + align_up(static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes, 256);
+    const size_t zero = static_cast<size_t>(plan->status - plan->zero_begin) +
+                        align_up(static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes, 256);
     if (int rc = clear_async(plan->zero_begin, zero, s)) return rc;
     if (class_starts_dev) {
         MRS_HIP_TRY(hipMemcpyAsync(plan->control->ghist, class_starts_dev, plan->radix * sizeof(uint32_t),

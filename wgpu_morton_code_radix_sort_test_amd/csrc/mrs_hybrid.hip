@@ -1,0 +1,478 @@
+// Kernels of the most-significant-digit-first schedule (see mrs_hybrid.hpp) for gfx950.
+#include "mrs_hybrid.hpp"
+
+#include "mrs_radix_pass.hpp"
+
+namespace mrs {
+
+// ---- 16-bit histogram ---------------------------------------------------------------------
+// One LDS atomic per key into 65536 counters of 16 bits, two to a word (128 KiB: one workgroup
+// of 1024 threads per compute unit), 16-byte nontemporal loads, four in flight per thread.  A
+// workgroup writes its table to `packed`; hybrid_reduce_kernel adds the tables up.  A counter that
+// wraps (65536 keys of one workgroup in one sub-bucket) loses 65535 or 65536 from the sum of the
+// fields, never gains: a workgroup whose fields do not add up to the keys it counted raises
+// hdr->overflow, and the decision kernel then chooses the other schedule, which such an input
+// needs anyway.
+__global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                 uint32_t vectors, uint32_t shift,
+                                                                 uint32_t* __restrict__ packed, HybridHeader* hdr)
+{
+    constexpr int THREADS = 1024, UNROLL = 4;
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kHybPackedWords];
+    __shared__ int s_diff;
+    const uint32_t tid = threadIdx.x;
+    {
+        uint4* z = reinterpret_cast<uint4*>(s_cnt);
+        for (uint32_t j = tid; j < kHybPackedWords / 4; j += THREADS) z[j] = make_uint4(0, 0, 0, 0);
+    }
+    if (tid == 0) s_diff = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    auto count = [&](uint32_t k) {
+        const uint32_t b = __builtin_amdgcn_ubfe(k, shift, 16);
+        atomicAdd(&s_cnt[b >> 1], 1u << ((b & 1u) * 16u));
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* __restrict__ vkeys = reinterpret_cast<const u32x4*>(keys);
+    const uint32_t stride = gridDim.x * THREADS;
+    uint32_t v = blockIdx.x * THREADS + tid;
+    // v + 3 * stride < 2^28 + 3 * 2^18: no wrap for any n < 2^32
+    for (; v + (UNROLL - 1) * stride < vectors; v += UNROLL * stride) {
+        u32x4 x[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) x[u] = __builtin_nontemporal_load(vkeys + v + u * stride);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            count(x[u].x); count(x[u].y); count(x[u].z); count(x[u].w);
+        }
+        mine += 4 * UNROLL;
+    }
+    for (; v < vectors; v += stride) {
+        const u32x4 x = __builtin_nontemporal_load(vkeys + v);
+        count(x.x); count(x.y); count(x.z); count(x.w);
+        mine += 4;
+    }
+    // what the vectors do not cover: everything if the array is not 16-byte aligned, else < 4 keys
+    for (unsigned long long i = static_cast<unsigned long long>(vectors) * 4 + blockIdx.x * THREADS + tid; i < n; i += stride) {
+        count(keys[i]);
+        mine += 1;
+    }
+    __syncthreads();
+    uint32_t fields = 0;
+    {
+        const uint4* c = reinterpret_cast<const uint4*>(s_cnt);
+        uint4* out = reinterpret_cast<uint4*>(packed + static_cast<size_t>(blockIdx.x) * kHybPackedWords);
+        for (uint32_t j = tid; j < kHybPackedWords / 4; j += THREADS) {
+            const uint4 w = c[j];
+            out[j] = w;
+            fields += (w.x & 0xFFFFu) + (w.x >> 16) + (w.y & 0xFFFFu) + (w.y >> 16) + (w.z & 0xFFFFu) + (w.z >> 16) +
+                      (w.w & 0xFFFFu) + (w.w >> 16);
+        }
+    }
+    int diff = static_cast<int>(mine) - static_cast<int>(fields);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff += __shfl_down(diff, o);
+    if ((tid & 63u) == 0 && diff != 0) atomicAdd(&s_diff, diff);
+    __syncthreads();
+    if (tid == 0 && s_diff != 0) atomicOr(&hdr->overflow, 1u);
+}
+
+// counts[i] = sum over the workgroups' tables of field i.  One thread per packed word.
+__global__ __launch_bounds__(256) void hybrid_reduce_kernel(const uint32_t* __restrict__ packed, int grid,
+                                                             uint32_t* __restrict__ counts)
+{
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= kHybPackedWords) return;
+    uint32_t lo = 0, hi = 0;
+    int g = 0;
+    for (; g + 3 < grid; g += 4) {
+        uint32_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = packed[static_cast<size_t>(g + u) * kHybPackedWords + j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lo += w[u] & 0xFFFFu;
+            hi += w[u] >> 16;
+        }
+    }
+    for (; g < grid; ++g) {
+        const uint32_t w = packed[static_cast<size_t>(g) * kHybPackedWords + j];
+        lo += w & 0xFFFFu;
+        hi += w >> 16;
+    }
+    reinterpret_cast<uint2*>(counts)[j] = make_uint2(lo, hi);
+}
+
+// One workgroup: exclusive scan of the 65536 counts (thread t owns entries 64t .. 64t+63, a
+// quarter of bucket t / 4), bucket starts, the tile table of pass B and the decision.
+__global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, HybridHeader* hdr, uint32_t n,
+                                                            uint32_t tile_items, uint32_t cap, uint32_t force_mode)
+{
+    __shared__ uint32_t s_wsum[16];
+    __shared__ uint32_t s_bstart[kHybBuckets + 1];
+    __shared__ uint32_t s_tsum[4];
+    __shared__ uint32_t s_max;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t c[64];
+    {
+        const uint4* c4 = reinterpret_cast<const uint4*>(tb->counts) + tid * 16;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint4 x = c4[q];
+            c[4 * q] = x.x; c[4 * q + 1] = x.y; c[4 * q + 2] = x.z; c[4 * q + 3] = x.w;
+        }
+    }
+    uint32_t sum = 0, mx = 0;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) {
+        sum += c[q];
+        mx = c[q] > mx ? c[q] : mx;
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= static_cast<uint32_t>(o)) incl += y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t y = __shfl_down(mx, o);
+        mx = y > mx ? y : mx;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_max, mx);
+    uint32_t run = incl - sum;
+    for (uint32_t w = 0; w < 16; ++w)
+        if (w < wave) run += s_wsum[w];
+    if ((tid & 3u) == 0) s_bstart[tid >> 2] = run;
+    if (tid == 1023) s_bstart[kHybBuckets] = run + sum;
+    {
+        uint4* o4 = reinterpret_cast<uint4*>(tb->sub_start) + tid * 16;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            uint4 o;
+            o.x = run; run += c[4 * q];
+            o.y = run; run += c[4 * q + 1];
+            o.z = run; run += c[4 * q + 2];
+            o.w = run; run += c[4 * q + 3];
+            o4[q] = o;
+        }
+        if (tid == 1023) tb->sub_start[kHybSubs] = run;
+    }
+    __syncthreads();
+    uint32_t tiles = 0, tincl = 0;
+    if (tid < kHybBuckets) {
+        const uint32_t bs = s_bstart[tid];
+        const uint32_t cnt = s_bstart[tid + 1] - bs;
+        tiles = (cnt + tile_items - 1) / tile_items;
+        tb->bucket_start[tid] = bs;
+        tincl = tiles;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(tincl, o);
+            if (lane >= static_cast<uint32_t>(o)) tincl += y;
+        }
+        if (lane == 63) s_tsum[wave] = tincl;
+    }
+    if (tid == kHybBuckets) tb->bucket_start[kHybBuckets] = s_bstart[kHybBuckets];
+    __syncthreads();
+    if (tid < kHybBuckets) {
+        uint32_t off = tincl - tiles;
+        for (uint32_t w = 0; w < 4; ++w)
+            if (w < wave) off += s_tsum[w];
+        tb->first_tile[tid] = off;
+        if (tid == kHybBuckets - 1) {
+            const uint32_t total_tiles = off + tiles;
+            // counts that do not add up to n (a wrapped counter) are never acted on
+            const bool ok = s_max <= cap && hdr->overflow == 0 && s_bstart[kHybBuckets] == n && force_mode != kHybFallback;
+            tb->first_tile[kHybBuckets] = total_tiles;
+            hdr->num_tiles_b = ok ? total_tiles : 0u;
+            hdr->max_sub = s_max;
+            hdr->mode = ok ? kHybRun : kHybFallback;
+        }
+    }
+}
+
+// ---- chained-scan passes that the device switches on or off --------------------------------
+// The digit pass of mrs_radix_pass.hpp behind a gate (hdr->mode == run_if_mode), over the whole
+// array (pass A, or one of the plan's ordinary passes when the device chose those) or, SEG, over
+// the buckets pass A made: tile t belongs to the bucket b with first_tile[b] <= t < first_tile[b+1],
+// covers TILE elements from bucket_start[b] + (t - first_tile[b]) * TILE (fewer in the bucket's
+// last tile), and its chained scan starts at first_tile[b] with the sub-bucket starts of b as
+// digit bases.  PERSISTENT: the workgroup draws tiles until none is left.
+template <bool SEG, bool PERSISTENT, int THREADS, int KPT>
+__global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs a, const HybridHeader* __restrict__ hdr,
+                                                                  const HybridTables* __restrict__ tb,
+                                                                  const uint32_t run_if_mode)
+{
+    using S = PassShared<8, THREADS, KPT, uint32_t, uint32_t>;
+    __shared__ S sh;
+    __shared__ uint32_t s_seg[4];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t mode = hdr->mode;  // uniform
+    if (PERSISTENT && mode != run_if_mode) return;
+    const uint32_t num_tiles = SEG ? hdr->num_tiles_b : a.num_tiles;
+    uint32_t ft0 = 0, ft1 = 0, bs0 = 0, bs1 = 0;
+    if constexpr (SEG) {
+        if (tid < kHybBuckets) {
+            ft0 = tb->first_tile[tid];
+            ft1 = tb->first_tile[tid + 1];
+            bs0 = tb->bucket_start[tid];
+            bs1 = tb->bucket_start[tid + 1];
+        }
+    }
+    for (;;) {
+        if (tid == 0) {
+            // the gate word and the ticket travel together; a launch that is switched off
+            // wastes one ticket of a counter nobody else reads
+            const uint32_t t = draw_tile(a, num_tiles);
+            sh.tile = mode == run_if_mode ? t : 0xFFFFFFFFu;
+            sh.abort = 0;
+        }
+        for (int j = tid; j < S::WAVES * S::RADIX; j += THREADS) (&sh.wave_hist[0][0])[j] = 0;
+        __syncthreads();
+        const uint32_t tile = sh.tile;
+        if (tile >= num_tiles) return;  // uniform
+        if constexpr (SEG) {
+            if (tid < kHybBuckets && ft0 <= tile && tile < ft1) {  // exactly one thread: empty buckets have ft0 == ft1
+                s_seg[0] = tid;
+                s_seg[1] = ft0;
+                s_seg[2] = bs0;
+                s_seg[3] = bs1;
+            }
+            __syncthreads();
+            const uint32_t seg = s_seg[0], first = s_seg[1], start = s_seg[2], end = s_seg[3];
+            const uint32_t base = start + (tile - first) * static_cast<uint32_t>(S::TILE);
+            const uint32_t remaining = end - base;
+            PassArgs b = a;
+            b.digit_base = tb->sub_start + seg * 256u;
+            if (remaining >= static_cast<uint32_t>(S::TILE))
+                process_tile<kModeOnesweep, kRankAtomic, kMapNone, true, uint32_t>(b, sh, tile, S::TILE, base, first);
+            else
+                process_tile<kModeOnesweep, kRankAtomic, kMapNone, false, uint32_t>(b, sh, tile, remaining, base, first);
+        } else {
+            const uint32_t remaining = a.n - tile * static_cast<uint32_t>(S::TILE);
+            const unsigned long long base = static_cast<unsigned long long>(tile) * S::TILE;
+            if (remaining >= static_cast<uint32_t>(S::TILE))
+                process_tile<kModeOnesweep, kRankAtomic, kMapNone, true, uint32_t>(a, sh, tile, S::TILE, base, 0u);
+            else
+                process_tile<kModeOnesweep, kRankAtomic, kMapNone, false, uint32_t>(a, sh, tile, remaining, base, 0u);
+        }
+        if (!PERSISTENT) return;
+        __syncthreads();  // the tile's LDS image is dead
+    }
+}
+
+// ---- local sort -----------------------------------------------------------------------------
+// A workgroup takes sub-buckets blockIdx.x, blockIdx.x + gridDim.x, ...: at most THREADS * KPT
+// pairs each (the decision kernel saw to that), loaded in the element order of the digit pass
+// (wave w owns a contiguous slice, item i of lane l is element w*64*ku + i*64 + l, ku = items per
+// thread of THIS sub-bucket), sorted by two stable counting passes through LDS on bits
+// [shift, shift + bits1) and [shift + bits1, shift + bits1 + bits2), each at most 8 bits wide,
+// ranked like the digit pass (returning LDS atomics on per-wave counters, lane order), and
+// written back over the sub-bucket, which nobody else touches.
+template <int THREADS, int KPT>
+__global__ __launch_bounds__(THREADS) void hybrid_local_sort_kernel(uint32_t* __restrict__ keys,
+                                                                     uint32_t* __restrict__ vals,
+                                                                     const HybridHeader* __restrict__ hdr,
+                                                                     const HybridTables* __restrict__ tb,
+                                                                     const uint32_t shift, const uint32_t bits1,
+                                                                     const uint32_t bits2)
+{
+    constexpr int WAVES = THREADS / 64;
+    constexpr int RADIX = 256;
+    static_assert(THREADS >= RADIX, "one thread per digit in the scan");
+    __shared__ uint2 s_stage[THREADS * KPT];  // 60 KiB at 512 x 15: two workgroups fit a compute unit's 160 KiB
+    __shared__ uint32_t s_hist[2][WAVES][RADIX];
+    __shared__ uint32_t s_wsum[2][4];
+    if (hdr->mode != kHybRun) return;  // uniform
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t shifts[2] = {shift, shift + bits1};
+    const uint32_t widths[2] = {bits1, bits2};
+
+    uint32_t sub = blockIdx.x;
+    if (sub >= kHybSubs) return;
+    uint32_t start = tb->sub_start[sub], end = tb->sub_start[sub + 1];
+    for (;;) {
+        // bounds of the next sub-bucket: on their way while this one is sorted
+        const uint32_t nsub = sub + gridDim.x;
+        uint32_t nstart = 0, nend = 0;
+        if (nsub < kHybSubs) {
+            nstart = tb->sub_start[nsub];
+            nend = tb->sub_start[nsub + 1];
+        }
+        const uint32_t cnt = end - start;
+        if (cnt != 0) {  // uniform
+            const uint32_t ku = (cnt + THREADS - 1) / THREADS;
+            const uint32_t my_first = wave * 64u * ku + lane;
+            for (int j = tid; j < 2 * WAVES * RADIX; j += THREADS) (&s_hist[0][0][0])[j] = 0;
+            uint32_t key[KPT], val[KPT], pos[KPT];
+            const uint32_t* __restrict__ kin = keys + start;
+            const uint32_t* __restrict__ vin = vals + start;
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                key[i] = 0;
+                val[i] = 0;
+                pos[i] = 0;
+                if (static_cast<uint32_t>(i) < ku) {  // uniform
+                    const uint32_t e = my_first + i * 64u;
+                    if (e < cnt) {
+                        key[i] = kin[e];
+                        val[i] = vin[e];
+                    }
+                }
+            }
+            __syncthreads();  // the counters are zero
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t sh = shifts[h], wd = widths[h];
+                if (h == 1) {
+                    // the order pass 1 left in LDS, read back slice by slice
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i) {
+                        if (static_cast<uint32_t>(i) < ku) {
+                            const uint32_t e = my_first + i * 64u;
+                            if (e < cnt) {
+                                const uint2 kv = s_stage[e];
+                                key[i] = kv.x;
+                                val[i] = kv.y;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    if (static_cast<uint32_t>(i) < ku) {
+                        const uint32_t e = my_first + i * 64u;
+                        if (e < cnt) pos[i] = atomicAdd(&s_hist[h][wave][__builtin_amdgcn_ubfe(key[i], sh, wd)], 1u);
+                    }
+                }
+                __syncthreads();  // every key is counted (and, h == 1, every slot of the stage has been read)
+                uint32_t tot = 0, incl = 0;
+                uint32_t c[WAVES];
+                if (tid < RADIX) {
+#pragma unroll
+                    for (int w = 0; w < WAVES; ++w) c[w] = s_hist[h][w][tid];
+#pragma unroll
+                    for (int w = 0; w < WAVES; ++w) {
+                        const uint32_t x = c[w];
+                        c[w] = tot;
+                        tot += x;
+                    }
+                    incl = tot;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t y = __shfl_up(incl, o);
+                        if (lane >= static_cast<uint32_t>(o)) incl += y;
+                    }
+                    if (lane == 63) s_wsum[h][wave] = incl;
+                }
+                __syncthreads();  // the per-wave parts wait in registers for the digit's offset
+                if (tid < RADIX) {
+                    uint32_t off = incl - tot;
+                    for (uint32_t w = 0; w < 4; ++w)
+                        if (w < wave) off += s_wsum[h][w];
+#pragma unroll
+                    for (int w = 0; w < WAVES; ++w) s_hist[h][w][tid] = c[w] + off;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    if (static_cast<uint32_t>(i) < ku) {
+                        const uint32_t e = my_first + i * 64u;
+                        if (e < cnt)
+                            s_stage[pos[i] + s_hist[h][wave][__builtin_amdgcn_ubfe(key[i], sh, wd)]] = make_uint2(key[i], val[i]);
+                    }
+                }
+                __syncthreads();
+            }
+            uint32_t* __restrict__ kout = keys + start;
+            uint32_t* __restrict__ vout = vals + start;
+            for (uint32_t s = tid; s < cnt; s += THREADS) {
+                const uint2 kv = s_stage[s];
+                kout[s] = kv.x;
+                vout[s] = kv.y;
+            }
+            // No barrier: the next sub-bucket clears counters that were last read before the barrier
+            // above and writes the stage only after two more barriers.
+        }
+        if (nsub >= kHybSubs) break;
+        sub = nsub;
+        start = nstart;
+        end = nend;
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------
+size_t hybrid_tables_bytes() { return (sizeof(HybridTables) + 255) / 256 * 256; }
+size_t hybrid_packed_bytes(int grid) { return static_cast<size_t>(grid) * kHybPackedWords * sizeof(uint32_t); }
+
+int hybrid_histogram_grid(int num_cus, uint64_t n)
+{
+    // at least 16 vectors per thread: every workgroup ends with a 128 KiB table to write
+    uint64_t g = (n / 4 + 1024 * 16 - 1) / (1024 * 16);
+    if (g > static_cast<uint64_t>(num_cus)) g = num_cus;
+    return g == 0 ? 1 : static_cast<int>(g);
+}
+
+int hybrid_local_sort_grid(int num_cus) { return num_cus * 2; }  // 80 KiB of LDS each: two per compute unit
+
+int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, int grid, uint32_t* packed,
+                            HybridHeader* hdr, hipStream_t s)
+{
+    const uint32_t vectors = (reinterpret_cast<uintptr_t>(keys) & 15u) ? 0u : n / 4u;
+    hipLaunchKernelGGL(hybrid_histogram_kernel, dim3(grid), dim3(1024), 0, s, keys, n, vectors, shift, packed, hdr);
+    MRS_CHECK_LAUNCH("hybrid_histogram_kernel");
+    return MRS_OK;
+}
+
+int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridHeader* hdr, uint32_t n,
+                       uint32_t tile_items, uint32_t force_mode, hipStream_t s)
+{
+    hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(kHybPackedWords / 256), dim3(256), 0, s, packed, grid, tables->counts);
+    MRS_CHECK_LAUNCH("hybrid_reduce_kernel");
+    hipLaunchKernelGGL(hybrid_scan_kernel, dim3(1), dim3(1024), 0, s, tables, hdr, n, tile_items, kHybLocalCap, force_mode);
+    MRS_CHECK_LAUNCH("hybrid_scan_kernel");
+    return MRS_OK;
+}
+
+template <bool SEG, bool PERSISTENT>
+static int launch_pass_shape(int threads, int kpt, const PassArgs& a, const HybridHeader* hdr, const HybridTables* tables,
+                             uint32_t run_if_mode, uint32_t grid, hipStream_t s)
+{
+    if (threads == 1024 && kpt == 32)
+        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, PERSISTENT, 1024, 32>), dim3(grid), dim3(1024), 0, s, a, hdr, tables, run_if_mode);
+    else if (threads == 512 && kpt == 8)
+        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, PERSISTENT, 512, 8>), dim3(grid), dim3(512), 0, s, a, hdr, tables, run_if_mode);
+    else
+        return fail(MRS_ERR_UNSUPPORTED, "no gated pass kernel for %d threads x %d keys per thread", threads, kpt);
+    MRS_CHECK_LAUNCH("hybrid_pass_kernel");
+    return MRS_OK;
+}
+
+int hybrid_launch_pass(bool segmented, bool persistent, int threads, int kpt, const PassArgs& a, const HybridHeader* hdr,
+                       const HybridTables* tables, uint32_t run_if_mode, uint32_t grid, hipStream_t s)
+{
+    if (a.wide_status) return fail(MRS_ERR_UNSUPPORTED, "gated passes use 32-bit tile status words");
+    if (grid == 0) grid = 1;
+    if (segmented)
+        return persistent ? launch_pass_shape<true, true>(threads, kpt, a, hdr, tables, run_if_mode, grid, s)
+                          : launch_pass_shape<true, false>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
+    return persistent ? launch_pass_shape<false, true>(threads, kpt, a, hdr, tables, run_if_mode, grid, s)
+                      : launch_pass_shape<false, false>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
+}
+
+int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,
+                             uint32_t shift, uint32_t bits1, uint32_t bits2, int grid, hipStream_t s)
+{
+    if (bits1 == 0 || bits1 > 8 || bits2 == 0 || bits2 > 8)
+        return fail(MRS_ERR_UNSUPPORTED, "the local sort takes two digits of 1 to 8 bits");
+    hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreads, kHybLocalKpt>), dim3(grid), dim3(kHybLocalThreads), 0, s,
+                       keys, vals, hdr, tables, shift, bits1, bits2);
+    MRS_CHECK_LAUNCH("hybrid_local_sort_kernel");
+    return MRS_OK;
+}
+
+}  // namespace mrs

@@ -129,9 +129,20 @@ struct mrs_context {
     void* static_scratch;
 };
 
+namespace mrs {
+struct HybridHeader;
+struct HybridTables;
+}
+
 struct mrs_plan {
     mrs_context* ctx;
     mrs_plan_desc desc;
+    // MRS_ALGO_HYBRID: desc.algo reads MRS_ALGO_ONESWEEP and the plan carries the tables of
+    // mrs_hybrid.hpp behind its status words
+    bool hybrid;
+    mrs::HybridHeader* hyb_header;  // inside the block cleared per call, before the status words
+    mrs::HybridTables* hyb_tables;
+    uint32_t* hyb_packed;           // one packed 16-bit histogram per workgroup of the histogram kernel
     uint32_t radix_bits, radix, num_passes;
     uint32_t threads, kpt, tile_items;
     uint64_t max_tiles;

@@ -81,6 +81,10 @@ struct GlobalHistArgs {
     const uint8_t* digit_map;  // partition mode: one pass, digit = map[(key >> begin_bit) & map_mask]
     uint32_t map_mask;
     uint32_t* ghist;           // [num_passes][RADIX], must be zero
+    // optional: the kernel runs only if *gate == gate_value (a word an earlier kernel of the same
+    // stream wrote: the device's choice between two pass schedules, see mrs_hybrid.hip)
+    const uint32_t* gate;
+    uint32_t gate_value;
 };
 
 // One LDS counter set per workgroup, one LDS atomic per key and pass; the pass loop is
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(256) void global_histogram_kernel(const GlobalHistA
     constexpr int VEC = 16 / sizeof(KeyT);
     constexpr int UNROLL = 2;  // vectors in flight per thread
     __shared__ uint32_t s_hist[MAXP * RADIX];
+    if (a.gate && *a.gate != a.gate_value) return;  // uniform
     for (int j = threadIdx.x; j < MAXP * RADIX; j += 256) s_hist[j] = 0;
     __syncthreads();
 
@@ -212,6 +217,7 @@ __global__ __launch_bounds__(1024) void global_histogram_banked_kernel(const Glo
     constexpr int UNROLL = 4;  // vectors in flight per thread
     __shared__ uint32_t s_hist[B::COUNTERS * R];
     __shared__ uint8_t s_map[ALL ? 1 : kMaxMapEntries];  // partition mode: the digit table
+    if (a.gate && *a.gate != a.gate_value) return;  // uniform
     for (int j = threadIdx.x; j < B::COUNTERS * R; j += THREADS) s_hist[j] = 0;
     if constexpr (!ALL) {
         if (a.digit_map)

@@ -169,14 +169,16 @@ __device__ __forceinline__ void status_store(StatusT* p, StatusT v)
 }
 
 // Decoupled look-back, one window: the status words of one digit of the J tiles
-// first, first-1, ... are requested.  Tile 0 always publishes an inclusive prefix, so a
-// walk ends at it: slots that would fall below tile 0 re-read tile 0 and are never used.
+// first, first-1, ... are requested.  The first tile of a chain (`floor`: tile 0, or the first
+// tile of a segment when the pass runs one chain per segment) always publishes an inclusive
+// prefix, so a walk ends at it: slots that would fall below it re-read it and are never used.
 template <int RADIX, typename StatusT, int J>
-__device__ __forceinline__ void window_issue(const StatusT* status, int first, uint32_t digit, StatusT (&v)[J])
+__device__ __forceinline__ void window_issue(const StatusT* status, int first, uint32_t digit, StatusT (&v)[J],
+                                             int floor = 0)
 {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const int tj = max(first - j, 0);
+        const int tj = max(first - j, floor);
         if constexpr (sizeof(StatusT) == 4) {
             // at most 2^22 tiles of 256 words: the byte offset fits 32 bits
             const uint32_t off = (static_cast<uint32_t>(tj) * RADIX + digit) * 4u;
@@ -348,10 +350,15 @@ struct PassShared {
 };
 
 // Everything after the tile id is known.  FULL = the tile has TILE valid elements.
+// `tile_base`: index of the tile's first element in the arrays; `chain_first`: the first tile of
+// the chained scan this tile belongs to (0 when the whole input is one chain; the first tile of
+// the tile's segment when every segment of the input is scanned on its own, in which case
+// a.digit_base is the segment's).
 template <int MODE, int RANK, int MAP, bool FULL, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT,
           typename ValT>
 __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS, THREADS, KPT, KeyT, ValT>& sh,
-                                             const uint32_t tile, const uint32_t tile_valid)
+                                             const uint32_t tile, const uint32_t tile_valid,
+                                             const unsigned long long tile_base, const uint32_t chain_first)
 {
     using S = PassShared<BITS, THREADS, KPT, KeyT, ValT>;
     using SB = StatusBits<StatusT>;
@@ -368,7 +375,6 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const unsigned long long tile_base = static_cast<unsigned long long>(tile) * TILE;
     const uint32_t my_first = wave * 64 * KPT + lane;  // element of item 0 inside the tile
 
     // ---- load keys -------------------------------------------------------------------
@@ -439,7 +445,7 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
         if (MODE == kModeOnesweep) {
             // publish the aggregate as early as possible
             StatusT* mine = static_cast<StatusT*>(a.status) + static_cast<size_t>(tile) * RADIX + tid;
-            status_store<StatusT>(mine, (tile == 0 ? SB::kInclusive : SB::kAggregate) | tile_count);
+            status_store<StatusT>(mine, (tile == chain_first ? SB::kInclusive : SB::kAggregate) | tile_count);
         }
         incl = tile_count;
 #pragma unroll
@@ -480,13 +486,13 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     const bool in_walk = MODE == kModeOnesweep && tid < RADIX;
     const uint32_t lb_digit = tid;
     const StatusT* const status = static_cast<const StatusT*>(a.status);
-    const bool walker = in_walk && !(kAblate & (1 | 16)) && tile != 0;
+    const bool walker = in_walk && !(kAblate & (1 | 16)) && tile != chain_first;
     // of the walked digit: first output position in the whole array, count and offset in this tile
     uint32_t digit_base = 0;
     const uint32_t walk_count = tile_count, walk_off = tile_off;
     if (in_walk) digit_base = a.digit_base[lb_digit];
     StatusT lbv[J];
-    if (walker) window_issue<RADIX, StatusT, J>(status, static_cast<int>(tile) - 1, lb_digit, lbv);
+    if (walker) window_issue<RADIX, StatusT, J>(status, static_cast<int>(tile) - 1, lb_digit, lbv, static_cast<int>(chain_first));
 
     // ---- global base of every digit of this tile ------------------------------------
     if (MODE == kModeScatter) {
@@ -538,10 +544,10 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
         resolve_round();
         MRS_STAMP(11);
         while (__ballot(!done) != 0ull) {
-            if (!done) window_issue<RADIX, StatusT, J>(status, next, lb_digit, lbv);
+            if (!done) window_issue<RADIX, StatusT, J>(status, next, lb_digit, lbv, static_cast<int>(chain_first));
             resolve_round();
         }
-        // tile 0 has nothing before it
+        // the first tile of a chain has nothing before it
         if (in_walk && !walker) sh.gbase[lb_digit] = digit_base - walk_off + ((kAblate & 16) ? tile * walk_count : 0u);
         MRS_STAMP(12);
     }
@@ -748,7 +754,8 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
 // mrs_api.hip) and a wait that does starve ends in the time-out of the look-back, not in a hang.
 // With B = 0 there is one list: drawn tiles are always a prefix, the lowest unfinished tile is
 // always running, and one free slot anywhere is enough.
-__device__ __forceinline__ uint32_t draw_tile(const PassArgs& a)
+// `num_tiles`: tiles of this pass (a.num_tiles, or a count only the device knows).
+__device__ __forceinline__ uint32_t draw_tile(const PassArgs& a, const uint32_t num_tiles)
 {
     const uint32_t B = a.xcd_block;
     if (B == 0) return atomicAdd(a.tile_counter, 1u);
@@ -758,10 +765,11 @@ __device__ __forceinline__ uint32_t draw_tile(const PassArgs& a)
         const uint32_t list = (die + i) & (kTicketLists - 1);
         const uint32_t k = atomicAdd(a.tile_counter + list, 1u);
         const unsigned long long tile = (static_cast<unsigned long long>(k / B) * kTicketLists + list) * B + k % B;
-        if (tile < a.num_tiles) return static_cast<uint32_t>(tile);
+        if (tile < num_tiles) return static_cast<uint32_t>(tile);
     }
-    return a.num_tiles;  // not reached: as many workgroups as tiles
+    return num_tiles;  // only with more workgroups than tiles
 }
+__device__ __forceinline__ uint32_t draw_tile(const PassArgs& a) { return draw_tile(a, a.num_tiles); }
 
 // The scatter of the three-kernel pass has no chain, so any one-to-one map from workgroup to
 // tile will do.  Workgroups are dealt to the 8 dies round robin by index; this map gives the 8
@@ -810,9 +818,9 @@ __device__ __forceinline__ void run_digit_pass(const PassArgs& a, PassShared<BIT
     // vector compare followed by s_cselect_b32 on a stale SCC (tools/check_scc.py finds these).
     const uint32_t remaining = a.n - tile * static_cast<uint32_t>(S::TILE);
     if (remaining >= static_cast<uint32_t>(S::TILE))
-        process_tile<MODE, RANK, MAP, true, StatusT>(a, sh, tile, S::TILE);
+        process_tile<MODE, RANK, MAP, true, StatusT>(a, sh, tile, S::TILE, static_cast<unsigned long long>(tile) * S::TILE, 0u);
     else
-        process_tile<MODE, RANK, MAP, false, StatusT>(a, sh, tile, remaining);
+        process_tile<MODE, RANK, MAP, false, StatusT>(a, sh, tile, remaining, static_cast<unsigned long long>(tile) * S::TILE, 0u);
 }
 
 template <int MODE, int RANK, int MAP, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
