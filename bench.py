@@ -4,8 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
 
 One step = one sort of the resident batch: 2^28 (30-bit Morton key, u32 index)
-pairs per GPU, 8-bit digits, onesweep passes, full 32 key bits.  Inputs are
-synthetic: points from the library's counter-based generator (seed 7) encoded to
+pairs per GPU through an MRS_ALGO_HYBRID plan over key bits [0, 30): a 16-bit
+histogram, two chained-scan scatters by the top two 8-bit digits and a sort of
+the 65536 sub-buckets inside LDS (three moves of every pair; the device falls
+back to four 8-bit passes on keys that are not spread well enough, which the
+line reports as `schedule`).  `--algo onesweep` times the four least-significant-
+digit-first passes over all 32 key bits instead.  Inputs are synthetic: points from the library's counter-based generator (seed 7) encoded to
 Morton keys on the GPU before the timed region.  Every step sorts a FRESH
 unsorted buffer from a pool built beforehand (sorting mutates its input, and
 re-sorting sorted data would be a different workload), so the timed region
@@ -17,8 +21,9 @@ histogram, RCCL all-reduce + all-gather, splitter, local partition pass,
 all-to-all-v exchange over xGMI, local sort (weak scaling: 2^31 pairs at N = 8).
 
 Rank 0 prints one JSON line.  `value` is whole-job Gkeys/s.  `roofline` is for
-the dominant kernel (one onesweep digit pass: 16 algorithmic bytes per pair per
-launch) timed with HIP events on the launch stream; `cpu_baseline` is
+the dominant kernel (the chained-scan digit pass: 16 algorithmic bytes per pair per
+launch; two launches per hybrid sort, four per onesweep sort) timed with HIP events
+on the launch stream; `cpu_baseline` is
 __gnu_parallel::sort of the whole step input on the host cores (N = 1 only);
 `c4` is the same sort at 2^30 pairs (N = 1 only, when memory allows).
 """
@@ -48,7 +53,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=28, help="pairs per GPU = 2^log2n")
-    ap.add_argument("--algo", default="onesweep", choices=["onesweep", "three_kernel"])
+    ap.add_argument("--algo", default="hybrid", choices=["hybrid", "onesweep", "three_kernel"])
+    ap.add_argument("--end-bit", type=int, default=0,
+                    help="one past the last key bit sorted on (0: 30 for --algo hybrid, whose keys are 30-bit codes, else 32)")
     ap.add_argument("--digit-bits", type=int, default=8)
     ap.add_argument("--tile-items", type=int, default=0)
     ap.add_argument("--pool", type=int, default=0, help="distinct unsorted inputs (0 = steps + warmup, capped by memory)")
@@ -144,6 +151,7 @@ def c4_leg(ctx, log2n=30, sorts=3):
         "per_pass_ms": [round(float(x), 4) for x in passes],
         "pass_frac_16B": PASS_BYTES_PER_PAIR * n / (float(np.mean(passes)) * 1e-3) / HBM_PEAK_BYTES_PER_S,
         "tile_status_words": "64-bit",
+        "algo": "onesweep: four passes over all 32 key bits (the three-move schedule needs sub-buckets of at most 7680 pairs, n / 65536 here is above that)",
         "timing": f"HIP events recorded by the library around every launch of {sorts} sorts after 1 warm-up",
         "verified": bool(ok),
     }
@@ -180,7 +188,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = mrs.Context(local_rank)
     n = 1 << args.log2n
-    algo = mrs.ALGO_ONESWEEP if args.algo == "onesweep" else mrs.ALGO_THREE_KERNEL
+    algo = {"hybrid": mrs.ALGO_HYBRID, "onesweep": mrs.ALGO_ONESWEEP}.get(args.algo, mrs.ALGO_THREE_KERNEL)
+    end_bit = args.end_bit or (30 if algo == mrs.ALGO_HYBRID else 32)
 
     total_steps = args.steps + args.warmup
     free_b, _ = torch.cuda.mem_get_info()
@@ -212,7 +221,7 @@ def main():
             k, i = inputs[j % pool]
             return sorter.sort(k, i)
     else:
-        plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=args.digit_bits, algo=algo,
+        plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=args.digit_bits, end_bit=end_bit, algo=algo,
                             tile_items=args.tile_items)
         inputs = [make_input(ctx, n, SEED + j) for j in range(pool)]
         kb = torch.empty(n, dtype=torch.int32, device=ctx.device)
@@ -272,24 +281,33 @@ def main():
     # ---- roofline of the dominant kernel: HIP events on the launch stream ----------------------
     roofline = None
     extra = {}
-    if not distributed and algo == mrs.ALGO_ONESWEEP:
+    if not distributed and algo in (mrs.ALGO_ONESWEEP, mrs.ALGO_HYBRID):
+        hybrid = algo == mrs.ALGO_HYBRID
+        pass_labels = ("msd_pass_a", "msd_pass_b") if hybrid else ("onesweep_pass",)
+        hist_label = "msd_histogram" if hybrid else "global_histogram"
         plan.set_timing(True)
-        pass_ms, hist_ms, sort_ms = [], [], []
+        pass_ms, hist_ms, sort_ms, launches = [], [], [], {}
         fresh = [make_input(ctx, n, SEED + 500 + j) for j in range(3)]
         for k, i in fresh:
             plan.sort_pairs(k, i, kb, vb)
             tm = plan.timings()
-            pass_ms += [ms for lab, ms in tm if lab == "onesweep_pass"]
-            hist_ms += [ms for lab, ms in tm if lab == "global_histogram"]
+            pass_ms += [ms for lab, ms in tm if lab in pass_labels]
+            hist_ms += [ms for lab, ms in tm if lab == hist_label]
             sort_ms.append(sum(ms for _, ms in tm))
+            for lab, ms in tm:
+                launches.setdefault(lab, []).append(ms)
         plan.set_timing(False)
+        schedule, largest = plan.schedule()
         del fresh
         avg_pass = float(np.mean(pass_ms)) * 1e-3
         achieved = PASS_BYTES_PER_PAIR * n / avg_pass / 1e9
         traffic = load_traffic()
+        if traffic and hybrid:
+            traffic = traffic.get("hybrid_pass") or None
         roofline = {
             "bound": "hbm",
-            "kernel": "digit_pass_kernel<onesweep>",
+            "kernel": "hybrid_pass_kernel (the chained-scan digit pass: pass A over the array, pass B bucket by bucket)"
+                      if hybrid else "digit_pass_kernel<onesweep>",
             "achieved": achieved,
             "peak": HBM_PEAK_BYTES_PER_S / 1e9,
             "unit": "GB/s",
@@ -302,12 +320,22 @@ def main():
             "avg_launch_ms": avg_pass * 1e3,
         }
         extra = {
-            "per_pass_ms": [round(float(x), 4) for x in pass_ms[-plan.info.num_passes:]],
+            "per_pass_ms": [round(float(x), 4) for x in pass_ms[-(2 if hybrid else plan.info.num_passes):]],
             "global_histogram_ms": round(float(np.mean(hist_ms)), 4),
             "global_histogram_GBps": 4.0 * n / (float(np.mean(hist_ms)) * 1e-3) / 1e9,
             "sort_event_ms": round(float(np.mean(sort_ms)), 4),
             "sort_roofline_frac_68B": SORT_BYTES_PER_PAIR * n / (float(np.mean(sort_ms)) * 1e-3) / HBM_PEAK_BYTES_PER_S,
         }
+        if hybrid:
+            # every launch of one sort, mean of three: both schedules are enqueued, the one the
+            # device did not choose returns at once (its launches are the sub-0.01 ms entries)
+            extra["launch_ms"] = {lab: round(float(np.mean(v)) * (len(v) / 3.0), 4) for lab, v in launches.items()}
+            extra["schedule"] = {0: "passes", 1: "msd", 2: "msd refused by the device"}[schedule]
+            extra["largest_sub_bucket"] = largest
+            local = float(np.mean(launches.get("msd_local_sort", [0.0]))) * 1e-3
+            if local > 0:
+                extra["local_sort_frac_16B"] = PASS_BYTES_PER_PAIR * n / local / HBM_PEAK_BYTES_PER_S
+            extra["moved_bytes_per_pair"] = 4 + 3 * 16  # what this schedule reads and writes; the 68 above is the metric's figure
         # Morton encode, reported separately: 12 B read + 8 B written per point
         xyz = ctx.generate_points(SEED, n)
         mn, mx = xyz.amin(dim=0).cpu().numpy(), xyz.amax(dim=0).cpu().numpy()
@@ -385,7 +413,7 @@ def main():
 
     c4 = None
     c5_one_gpu = None
-    if rank == 0 and not distributed and not args.no_c4 and algo == mrs.ALGO_ONESWEEP and args.log2n == 28:
+    if rank == 0 and not distributed and not args.no_c4 and algo in (mrs.ALGO_ONESWEEP, mrs.ALGO_HYBRID) and args.log2n == 28:
         # free the pool first: the 2^30 leg wants about 45 GiB
         del inputs, kb, vb, out
         if restore:
@@ -419,7 +447,7 @@ def main():
             "config": {
                 "workload": f"2^{args.log2n} (30-bit Morton key, u32 index) pairs per GPU from uniform random 3D points, "
                             + (f"8-bit digits over key bits [0, 30), onesweep local sorts" if distributed else
-                               f"{args.digit_bits}-bit digits over all 32 key bits, {args.algo}"),
+                               f"{args.digit_bits}-bit digits over key bits [0, {end_bit}), {args.algo}"),
                 "pairs_per_gpu": n,
                 "total_pairs": total_pairs,
                 "digit_bits": args.digit_bits,

@@ -151,6 +151,17 @@ int mrs_plan_check(mrs_plan* plan, void* stream);
  * harnesses (the reference has no counterpart: it always runs every pass,
  * src/main.rs:594-665). */
 int mrs_plan_get_passes_left_out(mrs_plan* plan, void* stream, uint32_t* left_out_mask);
+/* Synchronises `stream` and reports which pass schedule the most recent sort call on `plan`
+ * ran: MRS_SCHEDULE_PASSES (every plan but MRS_ALGO_HYBRID ones, and inputs too small for the
+ * other schedule), MRS_SCHEDULE_MSD (an MRS_ALGO_HYBRID plan whose keys the device found spread
+ * well enough) or MRS_SCHEDULE_MSD_REFUSED (the device found a sub-bucket too large and ran the
+ * ordinary passes).  *largest_sub_bucket (may be NULL) receives the size of the largest of the
+ * 65536 sub-buckets the device counted, 0 when it counted none.  For tests and harnesses; the
+ * reference always runs its one schedule (src/main.rs:594-665). */
+#define MRS_SCHEDULE_PASSES 0
+#define MRS_SCHEDULE_MSD 1
+#define MRS_SCHEDULE_MSD_REFUSED 2
+int mrs_plan_get_schedule(mrs_plan* plan, void* stream, int32_t* schedule, uint32_t* largest_sub_bucket);
 
 /* Measurement hook (the reference has no timers; its passes are named for an
  * external profiler, src/main.rs:583-662).  With timing enabled, mrs_sort_pairs

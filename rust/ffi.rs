@@ -10,6 +10,10 @@ use std::ffi::{c_char, c_int, c_void, CStr};
 pub const MRS_OK: c_int = 0;
 pub const ALGO_THREE_KERNEL: i32 = 0;
 pub const ALGO_ONESWEEP: i32 = 1;
+pub const ALGO_HYBRID: i32 = 2;
+pub const SCHEDULE_PASSES: i32 = 0;
+pub const SCHEDULE_MSD: i32 = 1;
+pub const SCHEDULE_MSD_REFUSED: i32 = 2;
 pub const MORTON_UNIFORMS_BYTES: usize = 51248;
 
 #[repr(C)]
@@ -99,6 +103,8 @@ extern "C" {
     pub fn mrs_plan_get_info(plan: *const mrs_plan, info: *mut PlanInfo) -> c_int;
     pub fn mrs_plan_check(plan: *mut mrs_plan, stream: *mut c_void) -> c_int;
     pub fn mrs_plan_get_passes_left_out(plan: *mut mrs_plan, stream: *mut c_void, left_out_mask: *mut u32) -> c_int;
+    pub fn mrs_plan_get_schedule(plan: *mut mrs_plan, stream: *mut c_void, schedule: *mut i32,
+                                 largest_sub_bucket: *mut u32) -> c_int;
     pub fn mrs_plan_set_timing(plan: *mut mrs_plan, enable: c_int) -> c_int;
     pub fn mrs_plan_get_timings(plan: *mut mrs_plan, cap: c_int, ms_out: *mut f32, labels_out: *mut c_char,
                                 count_out: *mut c_int) -> c_int;

@@ -1,0 +1,241 @@
+"""GPU parity tests of MRS_ALGO_HYBRID plans: the most-significant-digit-first schedule and the
+ordinary passes the device falls back to, through the C ABI, bit for bit against the CPU checker's
+stable sort (a stable sort has one answer, whatever the order of its passes)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import gpu_sort, to_dev, to_u32
+from inputs import DISTRIBUTIONS, make_keys, make_vals
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mrs():
+    import wgpu_morton_code_radix_sort_test_amd as m
+
+    return m
+
+
+@pytest.fixture()
+def small_inputs_take_the_schedule(monkeypatch):
+    """The library keeps inputs below 2^22 pairs on the ordinary passes; the checker is too slow
+    for more, so the tests lower the threshold (read by the library at every sort call)."""
+    monkeypatch.setenv("MRS_HYBRID_MIN_N", "1")
+
+
+def _sort_with_plan(ctx, mrs, keys, vals, n, begin, end, capacity=None, tile_items=0, indexed=False):
+    plan = mrs.SortPlan(ctx, capacity or n, key_words=1, payload_bytes=4, digit_bits=8, begin_bit=begin, end_bit=end,
+                        algo=mrs.ALGO_HYBRID, tile_items=tile_items)
+    ka, va = to_dev(keys, ctx.device), to_dev(vals, ctx.device)
+    if indexed:
+        va.fill_(0x3C3C3C3C)
+    kb, vb = torch.full_like(ka, -1), torch.full_like(va, -1)
+    in_b = plan.sort_pairs_indexed(ka, va, kb, vb, n=n) if indexed else plan.sort_pairs(ka, va, kb, vb, n=n)
+    plan.check()
+    schedule, largest = plan.schedule()
+    ko, vo = to_u32(kb if in_b else ka)[:n], to_u32(vb if in_b else va)[:n]
+    plan.close()
+    return ko, vo, in_b, schedule, largest
+
+
+# sizes around the tile (4096 and 32768 keys) and workgroup (512) boundaries of the three kernels
+SIZES = [4097, 4608, 5000, 8191, 8192, 8193, 32767, 32768, 32769, 65536, 100003, 262144 + 511, (1 << 20) + 123]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_schedule_matches_oracle(ctx, oracle, mrs, small_inputs_take_the_schedule, n):
+    """30-bit Morton keys of uniform points and uniform 32-bit keys: the device takes the new schedule."""
+    for dist, end in (("morton30", 30), ("random", 32)):
+        keys = make_keys(oracle, n, 1, dist, seed=n)
+        vals = make_vals(oracle, n, 1)
+        ko, vo, in_b, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 0, end)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, end)
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD, (dist, largest)
+        assert not in_b  # four passes' side
+        assert np.array_equal(ko, rk), (n, dist, "keys")
+        assert np.array_equal(vo, rv), (n, dist, "payload")
+
+
+@pytest.mark.parametrize("dist", DISTRIBUTIONS)
+def test_every_distribution_either_schedule(ctx, oracle, mrs, small_inputs_take_the_schedule, dist):
+    """Whatever the device decides (equal keys, one live digit and few distinct keys overflow a
+    sub-bucket and make it refuse), the result is the stable sort."""
+    n = 300007
+    keys = make_keys(oracle, n, 1, dist)
+    vals = make_vals(oracle, n, 1)
+    ko, vo, in_b, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 0, 32)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+    assert schedule in (mrs.SortPlan.SCHEDULE_MSD, mrs.SortPlan.SCHEDULE_MSD_REFUSED)
+    if dist in ("all_equal", "one_hot_digit", "few_distinct"):
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD_REFUSED and largest > 7680, (dist, largest)
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv), dist
+    # the reference-structured pass loop of the checker agrees (src/main.rs:594-665 restated)
+    lk, lv, _ = oracle.lsd_sort(keys, vals, n, 1, 1, 8, 0, 32, 256)
+    assert np.array_equal(ko, lk) and np.array_equal(vo, lv)
+
+
+def test_sub_buckets_at_the_capacity(ctx, oracle, mrs, small_inputs_take_the_schedule):
+    """One sub-bucket of exactly 7680 pairs (the most a workgroup sorts) is taken; 7681 are refused."""
+    for size, want in ((7680, "msd"), (7681, "refused")):
+        n = size + 50000
+        rnd = oracle.gen_u32(3, 9, n)
+        keys = rnd.copy()
+        keys[:size] = (np.uint32(0xABCD) << np.uint32(16)) | (rnd[:size] & np.uint32(0xFFFF))
+        others = keys[size:]
+        others[(others >> np.uint32(16)) == np.uint32(0xABCD)] ^= np.uint32(0x80000000)
+        perm = np.random.RandomState(5).permutation(n)
+        keys = np.ascontiguousarray(keys[perm])
+        vals = make_vals(oracle, n, 1)
+        ko, vo, _, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 0, 32)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+        assert largest == size
+        assert schedule == (mrs.SortPlan.SCHEDULE_MSD if want == "msd" else mrs.SortPlan.SCHEDULE_MSD_REFUSED)
+        assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+@pytest.mark.parametrize("begin,end", [(0, 25), (0, 27), (3, 29), (2, 32), (7, 32), (0, 31)])
+def test_bit_ranges(ctx, oracle, mrs, small_inputs_take_the_schedule, begin, end):
+    """Bits outside [begin, end) are carried along untouched and never compared."""
+    n = 150001
+    keys = make_keys(oracle, n, 1, "random", seed=end * 32 + begin)
+    vals = make_vals(oracle, n, 1)
+    ko, vo, in_b, schedule, _ = _sort_with_plan(ctx, mrs, keys, vals, n, begin, end)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, begin, end)
+    assert schedule == mrs.SortPlan.SCHEDULE_MSD and not in_b
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+def test_device_refusal_can_be_forced(ctx, oracle, mrs, small_inputs_take_the_schedule, monkeypatch):
+    """The gated ordinary passes (persistent workgroups drawing tiles) on keys that would have taken
+    the new schedule."""
+    monkeypatch.setenv("MRS_HYBRID_FORCE_FALLBACK", "1")
+    for n in (4097, 70001, 300000, (1 << 20) + 5):
+        keys = make_keys(oracle, n, 1, "morton30", seed=n)
+        vals = make_vals(oracle, n, 1)
+        ko, vo, in_b, schedule, _ = _sort_with_plan(ctx, mrs, keys, vals, n, 0, 30)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 30)
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD_REFUSED and not in_b
+        assert np.array_equal(ko, rk) and np.array_equal(vo, rv), n
+
+
+def test_indexed_sort_and_plan_reuse(ctx, oracle, mrs, small_inputs_take_the_schedule):
+    """mrs_sort_pairs_indexed on a hybrid plan (pass A makes the indices up), then the same plan on
+    smaller and differently distributed inputs: nothing of one call survives into the next."""
+    cap = 400000
+    plan = mrs.SortPlan(ctx, cap, key_words=1, payload_bytes=4, digit_bits=8, end_bit=32, algo=mrs.ALGO_HYBRID)
+    for n, dist, indexed in ((400000, "random", True), (123457, "all_equal", False), (399999, "morton30", True),
+                             (5000, "random", False), (3000, "random", True), (250000, "few_distinct", True),
+                             (400000, "random", False)):
+        keys = make_keys(oracle, n, 1, dist, seed=n)
+        vals = np.arange(n, dtype=np.uint32) if indexed else make_vals(oracle, n, 1)
+        ka, va = to_dev(keys, ctx.device), to_dev(vals, ctx.device)
+        if indexed:
+            va.fill_(0x77777777)
+        kb, vb = torch.full_like(ka, -1), torch.full_like(va, -1)
+        in_b = plan.sort_pairs_indexed(ka, va, kb, vb, n=n) if indexed else plan.sort_pairs(ka, va, kb, vb, n=n)
+        plan.check()
+        schedule, _ = plan.schedule()
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+        assert not in_b
+        if n <= 4096:
+            assert schedule == plan.SCHEDULE_PASSES  # the one-workgroup sort
+        assert np.array_equal(to_u32(ka)[:n], rk) and np.array_equal(to_u32(va)[:n], rv), (n, dist, indexed)
+    plan.close()
+
+
+def test_small_inputs_stay_on_the_ordinary_passes(ctx, oracle, mrs):
+    """Without the test switch an input below 2^22 pairs never sees the new schedule."""
+    n = 200000
+    keys = make_keys(oracle, n, 1, "random")
+    vals = make_vals(oracle, n, 1)
+    ko, vo, in_b, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 0, 32)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+    assert schedule == mrs.SortPlan.SCHEDULE_PASSES and largest == 0 and not in_b
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+def test_misaligned_buffers(ctx, oracle, mrs, small_inputs_take_the_schedule):
+    """Key and payload arrays that start 4 bytes past a 16-byte boundary."""
+    n = 200003
+    keys = make_keys(oracle, n, 1, "random", seed=11)
+    vals = make_vals(oracle, n, 1)
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, algo=mrs.ALGO_HYBRID)
+    bufs = [torch.zeros(n + 4, dtype=torch.int32, device=ctx.device) for _ in range(4)]
+    ka, va, kb, vb = (b[1:n + 1] for b in bufs)
+    ka.copy_(to_dev(keys, ctx.device))
+    va.copy_(to_dev(vals, ctx.device))
+    in_b = plan.sort_pairs(ka, va, kb, vb)
+    plan.check()
+    assert plan.schedule()[0] == plan.SCHEDULE_MSD and not in_b
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+    assert np.array_equal(to_u32(ka), rk) and np.array_equal(to_u32(va), rv)
+    for b in bufs:  # nothing written outside the slices
+        assert int(b[0]) == 0 and int(b[n + 1]) == 0
+    plan.close()
+
+
+def test_replays_from_a_graph(ctx, oracle, mrs, small_inputs_take_the_schedule):
+    """Both schedules are enqueued by every call, so one captured call serves inputs of either kind."""
+    n = 150000
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, algo=mrs.ALGO_HYBRID)
+    ka = torch.zeros(n, dtype=torch.int32, device=ctx.device)
+    va, kb, vb = torch.zeros_like(ka), torch.zeros_like(ka), torch.zeros_like(ka)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ka.copy_(to_dev(make_keys(oracle, n, 1, "random", seed=1), ctx.device))
+        plan.sort_pairs(ka, va, kb, vb, stream=side)  # warm-up outside the capture
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        in_b = plan.sort_pairs(ka, va, kb, vb, stream=torch.cuda.current_stream())
+    assert not in_b
+    for dist in ("random", "all_equal", "morton30", "few_distinct", "random"):
+        keys = make_keys(oracle, n, 1, dist, seed=3)
+        vals = make_vals(oracle, n, 1)
+        ka.copy_(to_dev(keys, ctx.device))
+        va.copy_(to_dev(vals, ctx.device))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+        assert np.array_equal(to_u32(ka), rk) and np.array_equal(to_u32(va), rv), dist
+    plan.check()
+    del graph
+    plan.close()
+
+
+def test_unsupported_shapes_are_refused(ctx, mrs):
+    from wgpu_morton_code_radix_sort_test_amd._lib import MrsError
+
+    for kwargs in (dict(key_words=2), dict(payload_bytes=0), dict(payload_bytes=16), dict(digit_bits=4),
+                   dict(end_bit=24), dict(begin_bit=10, end_bit=30), dict(tile_items=8192)):
+        args = dict(key_words=1, payload_bytes=4, digit_bits=8, algo=mrs.ALGO_HYBRID)
+        args.update(kwargs)
+        with pytest.raises(MrsError):
+            mrs.SortPlan(ctx, 100000, **args)
+    with pytest.raises(MrsError):
+        mrs.SortPlan(ctx, 1 << 30, key_words=1, payload_bytes=4, digit_bits=8, algo=mrs.ALGO_HYBRID)
+
+
+def test_fuzz(ctx, oracle, mrs, small_inputs_take_the_schedule):
+    """Seeded random sizes, bit ranges, distributions and payload modes on hybrid plans."""
+    rng = np.random.RandomState(20241112)
+    for case in range(40):
+        n = int(rng.choice([rng.randint(4097, 9000), rng.randint(9000, 70000), rng.randint(70000, 500000)]))
+        width = int(rng.randint(25, 33))
+        begin = int(rng.randint(0, 32 - width + 1))
+        end = begin + width
+        dist = DISTRIBUTIONS[rng.randint(len(DISTRIBUTIONS))]
+        indexed = bool(rng.randint(2))
+        tile = int(rng.choice([0, 4096, 32768]))
+        keys = make_keys(oracle, n, 1, dist, seed=case)
+        vals = np.arange(n, dtype=np.uint32) if indexed else make_vals(oracle, n, 1)
+        ko, vo, in_b, schedule, _ = _sort_with_plan(ctx, mrs, keys, vals, n, begin, end, tile_items=tile, indexed=indexed)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, begin, end)
+        what = (case, n, begin, end, dist, indexed, tile, schedule)
+        assert not in_b, what
+        assert np.array_equal(ko, rk), what
+        assert np.array_equal(vo, rv), what

@@ -360,3 +360,14 @@ class SortPlan:
         mask = ctypes.c_uint32(0)
         _lib.check(self.lib.mrs_plan_get_passes_left_out(self._h, _stream(stream), ctypes.byref(mask)))
         return mask.value
+
+    SCHEDULE_PASSES = 0
+    SCHEDULE_MSD = 1
+    SCHEDULE_MSD_REFUSED = 2
+
+    def schedule(self, stream=None):
+        """`mrs_plan_get_schedule`: synchronises; (schedule the last sort ran, largest sub-bucket the
+        device counted).  Only ALGO_HYBRID plans ever report anything but SCHEDULE_PASSES."""
+        which, largest = ctypes.c_int32(0), ctypes.c_uint32(0)
+        _lib.check(self.lib.mrs_plan_get_schedule(self._h, _stream(stream), ctypes.byref(which), ctypes.byref(largest)))
+        return which.value, largest.value

@@ -702,6 +702,22 @@ extern "C" int mrs_plan_get_passes_left_out(mrs_plan* plan, void* stream, uint32
     return MRS_OK;
 }
 
+extern "C" int mrs_plan_get_schedule(mrs_plan* plan, void* stream, int32_t* schedule, uint32_t* largest_sub_bucket)
+{
+    clear_error();
+    if (!plan || !schedule) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_get_schedule: null argument");
+    if (int rc = check_device(plan->ctx, "mrs_plan_get_schedule")) return rc;
+    *schedule = MRS_SCHEDULE_PASSES;
+    if (largest_sub_bucket) *largest_sub_bucket = 0;
+    MRS_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (!plan->hyb_last) return MRS_OK;
+    HybridHeader h;
+    MRS_HIP_TRY(hipMemcpy(&h, plan->hyb_header, sizeof h, hipMemcpyDeviceToHost));
+    *schedule = h.mode == kHybRun ? MRS_SCHEDULE_MSD : MRS_SCHEDULE_MSD_REFUSED;
+    if (largest_sub_bucket) *largest_sub_bucket = h.max_sub;
+    return MRS_OK;
+}
+
 static int check_pair_buffers(const mrs_plan* plan, const void* ka, const void* va, const void* kb, const void* vb,
                               const char* who)
 {
@@ -796,6 +812,7 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     a.status = plan->status + region;
     a.tile_counter = plan->control->tile_counter[kMaxPasses - 1];
     a.index_payload = 0;
+    a.xcd_block = xcd_block * 2;  // chains end with their bucket: larger blocks cost less here (0.834 -> 0.822 ms at 2^28)
     if (int rc = hybrid_launch_pass(true, false, plan->threads, plan->kpt, a, plan->hyb_header, plan->hyb_tables, kHybRun,
                                     num_tiles + kHybBuckets, s))
         return rc;
@@ -851,6 +868,7 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
     const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
 
     plan->pass_plan_live = false;
+    plan->hyb_last = false;
     plan->num_marks = 0;
     if (int rc = mark(plan, "start", s)) return rc;
     // Small inputs: the whole sort in one launch of one workgroup (MRS_NO_SMALL_SORT=1: A/B aid).
@@ -872,7 +890,8 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
         if (int rc = launch_small_sort(plan->desc.key_words, plan->radix_bits, a, s)) return rc;
         return mark(plan, "small_sort", s);
     }
-    if (plan->hybrid && !primed && n >= hybrid_min_n())
+    plan->hyb_last = plan->hybrid && !primed && n >= hybrid_min_n();
+    if (plan->hyb_last)
         return sort_pairs_hybrid(plan, n32, keys_a, vals_a, keys_b, vals_b, s, indexed);
     // 64-bit keys: passes whose digit is the same for every key are left out on the device
     // (see global_histogram_scan_kernel; MRS_NO_PASS_SKIP=1: A/B aid)
@@ -1202,6 +1221,7 @@ int partition_internal(mrs_plan* plan, uint64_t n, const void* keys_in, const vo
     // the record of which passes the last sort left out no longer describes it
     plan->primed_keys = nullptr;
     plan->pass_plan_live = false;
+    plan->hyb_last = false;
     const uint32_t n32 = static_cast<uint32_t>(n);
     const uint32_t num_tiles = static_cast<uint32_t>((n + plan->tile_items - 1) / plan->tile_items);
     const size_t zero = static_cast<size_t>(plan->status - plan->zero_begin) +

@@ -273,8 +273,11 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
 // [shift, shift + bits1) and [shift + bits1, shift + bits1 + bits2), each at most 8 bits wide,
 // ranked like the digit pass (returning LDS atomics on per-wave counters, lane order), and
 // written back over the sub-bucket, which nobody else touches.
+constexpr uint32_t kLocalMinGrid = 256;  // so that a workgroup has at most this many sub-buckets
+constexpr uint32_t kLocalMaxPerGroup = kHybSubs / kLocalMinGrid;
+
 template <int THREADS, int KPT>
-__global__ __launch_bounds__(THREADS) void hybrid_local_sort_kernel(uint32_t* __restrict__ keys,
+__global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t* __restrict__ keys,
                                                                      uint32_t* __restrict__ vals,
                                                                      const HybridHeader* __restrict__ hdr,
                                                                      const HybridTables* __restrict__ tb,
@@ -284,124 +287,134 @@ __global__ __launch_bounds__(THREADS) void hybrid_local_sort_kernel(uint32_t* __
     constexpr int WAVES = THREADS / 64;
     constexpr int RADIX = 256;
     static_assert(THREADS >= RADIX, "one thread per digit in the scan");
-    __shared__ uint2 s_stage[THREADS * KPT];  // 60 KiB at 512 x 15: two workgroups fit a compute unit's 160 KiB
+    __shared__ __attribute__((aligned(16))) uint2 s_stage[THREADS * KPT];  // 60 KiB at 512 x 15: two workgroups fit a compute unit's 160 KiB
     __shared__ uint32_t s_hist[2][WAVES][RADIX];
     __shared__ uint32_t s_wsum[2][4];
-    if (hdr->mode != kHybRun) return;  // uniform
+    __shared__ uint32_t s_first[kLocalMaxPerGroup], s_count[kLocalMaxPerGroup];
+    if (hdr->mode != kHybRun || blockIdx.x >= kHybSubs) return;  // uniform
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t shifts[2] = {shift, shift + bits1};
     const uint32_t widths[2] = {bits1, bits2};
 
-    uint32_t sub = blockIdx.x;
-    if (sub >= kHybSubs) return;
-    uint32_t start = tb->sub_start[sub], end = tb->sub_start[sub + 1];
-    for (;;) {
-        // bounds of the next sub-bucket: on their way while this one is sorted
-        const uint32_t nsub = sub + gridDim.x;
-        uint32_t nstart = 0, nend = 0;
-        if (nsub < kHybSubs) {
-            nstart = tb->sub_start[nsub];
-            nend = tb->sub_start[nsub + 1];
+    // element i of this thread in a sub-bucket of `count` pairs, `per` to a thread
+    auto element = [&](uint32_t per, int i) __attribute__((always_inline)) { return wave * 64u * per + lane + i * 64u; };
+    // Straight-line on purpose: every item is loaded, items past the sub-bucket's end from its
+    // first element (one cache line for the whole wave; the value is never used).  Conditional
+    // loads into the arrays made the compiler copy whole arrays at every join.
+    auto load_bucket = [&](uint32_t (&key)[KPT], uint32_t (&val)[KPT], uint32_t first, uint32_t count) __attribute__((always_inline)) {
+        if (count == 0) return;  // uniform; sort_bucket does not look at the registers either
+        const uint32_t per = (count + THREADS - 1) / THREADS;
+        const uint32_t* __restrict__ kin = keys + first;
+        const uint32_t* __restrict__ vin = vals + first;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t e = element(per, i);
+            const uint32_t ec = (static_cast<uint32_t>(i) < per && e < count) ? e : 0u;
+            key[i] = kin[ec];
+            val[i] = vin[ec];
         }
-        const uint32_t cnt = end - start;
-        if (cnt != 0) {  // uniform
-            const uint32_t ku = (cnt + THREADS - 1) / THREADS;
-            const uint32_t my_first = wave * 64u * ku + lane;
-            for (int j = tid; j < 2 * WAVES * RADIX; j += THREADS) (&s_hist[0][0][0])[j] = 0;
-            uint32_t key[KPT], val[KPT], pos[KPT];
-            const uint32_t* __restrict__ kin = keys + start;
-            const uint32_t* __restrict__ vin = vals + start;
+    };
+    // sorts the `cnt` pairs held in (key, val) and writes them over [start, start + cnt)
+    auto sort_bucket = [&](uint32_t (&key)[KPT], uint32_t (&val)[KPT], const uint32_t start, const uint32_t cnt) __attribute__((always_inline)) {
+        if (cnt == 0) return;  // uniform
+        const uint32_t ku = (cnt + THREADS - 1) / THREADS;
+        PackedPos<KPT> pos;  // ranks and slots are below 2^13: two to a register
+        for (int j = tid; j < 2 * WAVES * RADIX; j += THREADS) (&s_hist[0][0][0])[j] = 0;
+        __syncthreads();  // the counters are zero (and every wave has left the previous write-out)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t sh = shifts[h], wd = widths[h];
+            if (h == 1) {
+                // the order pass 1 left in LDS, read back slice by slice
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    const uint32_t e = element(ku, i);
+                    const uint2 kv = s_stage[(static_cast<uint32_t>(i) < ku && e < cnt) ? e : 0u];  // straight-line, as the loads
+                    key[i] = kv.x;
+                    val[i] = kv.y;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                key[i] = 0;
-                val[i] = 0;
-                pos[i] = 0;
-                if (static_cast<uint32_t>(i) < ku) {  // uniform
-                    const uint32_t e = my_first + i * 64u;
-                    if (e < cnt) {
-                        key[i] = kin[e];
-                        val[i] = vin[e];
-                    }
-                }
+                uint32_t r = 0;
+                if (static_cast<uint32_t>(i) < ku && element(ku, i) < cnt)
+                    r = atomicAdd(&s_hist[h][wave][__builtin_amdgcn_ubfe(key[i], sh, wd)], 1u);
+                pos.set_fresh(i, r);
             }
-            __syncthreads();  // the counters are zero
+            __syncthreads();  // every key is counted (and, h == 1, every slot of the stage has been read)
+            uint32_t tot = 0, incl = 0;
+            uint32_t c[WAVES];
+            if (tid < RADIX) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t sh = shifts[h], wd = widths[h];
-                if (h == 1) {
-                    // the order pass 1 left in LDS, read back slice by slice
+                for (int w = 0; w < WAVES; ++w) c[w] = s_hist[h][w][tid];
 #pragma unroll
-                    for (int i = 0; i < KPT; ++i) {
-                        if (static_cast<uint32_t>(i) < ku) {
-                            const uint32_t e = my_first + i * 64u;
-                            if (e < cnt) {
-                                const uint2 kv = s_stage[e];
-                                key[i] = kv.x;
-                                val[i] = kv.y;
-                            }
-                        }
-                    }
+                for (int w = 0; w < WAVES; ++w) {
+                    const uint32_t x = c[w];
+                    c[w] = tot;
+                    tot += x;
                 }
+                incl = tot;
 #pragma unroll
-                for (int i = 0; i < KPT; ++i) {
-                    if (static_cast<uint32_t>(i) < ku) {
-                        const uint32_t e = my_first + i * 64u;
-                        if (e < cnt) pos[i] = atomicAdd(&s_hist[h][wave][__builtin_amdgcn_ubfe(key[i], sh, wd)], 1u);
-                    }
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t y = __shfl_up(incl, o);
+                    if (lane >= static_cast<uint32_t>(o)) incl += y;
                 }
-                __syncthreads();  // every key is counted (and, h == 1, every slot of the stage has been read)
-                uint32_t tot = 0, incl = 0;
-                uint32_t c[WAVES];
-                if (tid < RADIX) {
-#pragma unroll
-                    for (int w = 0; w < WAVES; ++w) c[w] = s_hist[h][w][tid];
-#pragma unroll
-                    for (int w = 0; w < WAVES; ++w) {
-                        const uint32_t x = c[w];
-                        c[w] = tot;
-                        tot += x;
-                    }
-                    incl = tot;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const uint32_t y = __shfl_up(incl, o);
-                        if (lane >= static_cast<uint32_t>(o)) incl += y;
-                    }
-                    if (lane == 63) s_wsum[h][wave] = incl;
-                }
-                __syncthreads();  // the per-wave parts wait in registers for the digit's offset
-                if (tid < RADIX) {
-                    uint32_t off = incl - tot;
-                    for (uint32_t w = 0; w < 4; ++w)
-                        if (w < wave) off += s_wsum[h][w];
-#pragma unroll
-                    for (int w = 0; w < WAVES; ++w) s_hist[h][w][tid] = c[w] + off;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < KPT; ++i) {
-                    if (static_cast<uint32_t>(i) < ku) {
-                        const uint32_t e = my_first + i * 64u;
-                        if (e < cnt)
-                            s_stage[pos[i] + s_hist[h][wave][__builtin_amdgcn_ubfe(key[i], sh, wd)]] = make_uint2(key[i], val[i]);
-                    }
-                }
-                __syncthreads();
+                if (lane == 63) s_wsum[h][wave] = incl;
             }
-            uint32_t* __restrict__ kout = keys + start;
-            uint32_t* __restrict__ vout = vals + start;
-            for (uint32_t s = tid; s < cnt; s += THREADS) {
-                const uint2 kv = s_stage[s];
-                kout[s] = kv.x;
-                vout[s] = kv.y;
+            __syncthreads();  // the per-wave parts wait in registers for the digit's offset
+            if (tid < RADIX) {
+                uint32_t off = incl - tot;
+                for (uint32_t w = 0; w < 4; ++w)
+                    if (w < wave) off += s_wsum[h][w];
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) s_hist[h][w][tid] = c[w] + off;
             }
-            // No barrier: the next sub-bucket clears counters that were last read before the barrier
-            // above and writes the stage only after two more barriers.
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                if (static_cast<uint32_t>(i) < ku && element(ku, i) < cnt)
+                    s_stage[pos.get(i) + s_hist[h][wave][__builtin_amdgcn_ubfe(key[i], sh, wd)]] = make_uint2(key[i], val[i]);
+            }
+            __syncthreads();
         }
-        if (nsub >= kHybSubs) break;
-        sub = nsub;
-        start = nstart;
-        end = nend;
+        // write-out, two slots per lane: one 16-byte LDS read, one 8-byte store each for keys and
+        // payload (a sub-bucket starts at any 4-byte boundary; gfx950 serves the wider store there).
+        // Four slots and 16-byte stores measured 2 % slower.
+        uint32_t* __restrict__ kout = keys + start;
+        uint32_t* __restrict__ vout = vals + start;
+        for (uint32_t s2 = 2u * tid; s2 < cnt; s2 += 2u * THREADS) {
+            if (s2 + 1 < cnt) {
+                const uint4 q = *reinterpret_cast<const uint4*>(&s_stage[s2]);
+                *reinterpret_cast<uint2*>(kout + s2) = make_uint2(q.x, q.z);
+                *reinterpret_cast<uint2*>(vout + s2) = make_uint2(q.y, q.w);
+            } else {
+                const uint2 kv = s_stage[s2];
+                kout[s2] = kv.x;
+                vout[s2] = kv.y;
+            }
+        }
+    };
+
+    // This workgroup's sub-buckets are blockIdx.x, + gridDim.x, ...: their bounds go to LDS once
+    // (a scalar load inside the loop would be waited for at the next LDS access).  Two register
+    // sets take turns: while one sub-bucket is sorted and written out, the pairs of the next are
+    // already on their way into the other set, so the workgroup always has loads in flight.
+    const uint32_t mine = (kHybSubs - 1u - blockIdx.x) / gridDim.x + 1u;  // blockIdx.x < kHybSubs
+    for (uint32_t j = tid; j < mine; j += THREADS) {
+        const uint32_t which = blockIdx.x + j * gridDim.x;
+        s_first[j] = tb->sub_start[which];
+        s_count[j] = tb->sub_start[which + 1] - tb->sub_start[which];
+    }
+    __syncthreads();
+    uint32_t key_a[KPT], val_a[KPT], key_b[KPT], val_b[KPT];
+    load_bucket(key_a, val_a, s_first[0], s_count[0]);
+    for (uint32_t j = 0;;) {
+        if (j + 1 < mine) load_bucket(key_b, val_b, s_first[j + 1], s_count[j + 1]);
+        sort_bucket(key_a, val_a, s_first[j], s_count[j]);
+        if (++j >= mine) break;
+        if (j + 1 < mine) load_bucket(key_a, val_a, s_first[j + 1], s_count[j + 1]);
+        sort_bucket(key_b, val_b, s_first[j], s_count[j]);
+        if (++j >= mine) break;
     }
 }
 
@@ -417,7 +430,12 @@ int hybrid_histogram_grid(int num_cus, uint64_t n)
     return g == 0 ? 1 : static_cast<int>(g);
 }
 
-int hybrid_local_sort_grid(int num_cus) { return num_cus * 2; }  // 80 KiB of LDS each: two per compute unit
+int hybrid_local_sort_grid(int num_cus)
+{
+    // 78 KiB of LDS each: two per compute unit
+    const int g = num_cus * 2;
+    return g < static_cast<int>(kLocalMinGrid) ? static_cast<int>(kLocalMinGrid) : g;
+}  // 80 KiB of LDS each: two per compute unit
 
 int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, int grid, uint32_t* packed,
                             HybridHeader* hdr, hipStream_t s)

@@ -143,6 +143,7 @@ struct mrs_plan {
     mrs::HybridHeader* hyb_header;  // inside the block cleared per call, before the status words
     mrs::HybridTables* hyb_tables;
     uint32_t* hyb_packed;           // one packed 16-bit histogram per workgroup of the histogram kernel
+    bool hyb_last;                  // the last sort call enqueued both schedules (hyb_header is its record)
     uint32_t radix_bits, radix, num_passes;
     uint32_t threads, kpt, tile_items;
     uint64_t max_tiles;
