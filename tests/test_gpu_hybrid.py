@@ -95,9 +95,12 @@ def test_sub_buckets_at_the_capacity(ctx, oracle, mrs, small_inputs_take_the_sch
         assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
 
 
-@pytest.mark.parametrize("begin,end", [(0, 25), (0, 27), (3, 29), (2, 32), (7, 32), (0, 31)])
-def test_bit_ranges(ctx, oracle, mrs, small_inputs_take_the_schedule, begin, end):
-    """Bits outside [begin, end) are carried along untouched and never compared."""
+@pytest.mark.parametrize("msd_bits", [14, 15, 16])
+@pytest.mark.parametrize("begin,end", [(0, 25), (0, 27), (3, 29), (2, 32), (7, 32), (0, 31), (0, 30)])
+def test_bit_ranges(ctx, oracle, mrs, small_inputs_take_the_schedule, monkeypatch, begin, end, msd_bits):
+    """Bits outside [begin, end) are carried along untouched and never compared; every split of the
+    leading bits between the two scatters (7 + 7, 8 + 7, 8 + 8; the library picks it from n)."""
+    monkeypatch.setenv("MRS_HYBRID_MSD_BITS", str(msd_bits))
     n = 150001
     keys = make_keys(oracle, n, 1, "random", seed=end * 32 + begin)
     vals = make_vals(oracle, n, 1)

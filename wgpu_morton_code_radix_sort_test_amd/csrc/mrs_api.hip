@@ -735,12 +735,32 @@ static int check_pair_buffers(const mrs_plan* plan, const void* ka, const void* 
     return MRS_OK;
 }
 
-// Inputs below this size take the plan's ordinary passes: the local sort visits 65536 sub-buckets
-// whatever n is (MRS_HYBRID_MIN_N: test aid, to run the schedule on inputs a checker can follow).
-static uint64_t hybrid_min_n()
+// Inputs below this size take the plan's ordinary passes: the local sort visits at least 2^14
+// sub-buckets whatever n is, 2^16 when more than 30 key bits are sorted, and each visit has a
+// latency of its own (measured break-even: 2^25.5 and 2^27 pairs).  MRS_HYBRID_MIN_N: test aid, to
+// run the schedule on inputs a checker can follow.
+static uint64_t hybrid_min_n(const mrs_plan* plan)
 {
     if (const char* e = std::getenv("MRS_HYBRID_MIN_N")) return std::strtoull(e, nullptr, 10);
-    return 1ull << 22;
+    const uint32_t width = plan->desc.end_bit - plan->desc.begin_bit;
+    return width <= 30 ? 1ull << 26 : (width == 31 ? 3ull << 25 : 1ull << 27);
+}
+
+// Key bits passes A and B take together: enough for sub-buckets of at most about 4096 pairs on
+// evenly spread keys, at least 14, and at least so many that 16 bits or fewer are left for the
+// local sort.  A takes the larger half.
+static uint32_t hybrid_msd_bits(const mrs_plan* plan, uint32_t n)
+{
+    const uint32_t width = plan->desc.end_bit - plan->desc.begin_bit;
+    uint32_t bits = 14;
+    while (bits < 16 && (static_cast<uint64_t>(n) >> bits) > 4096) ++bits;
+    // MRS_HYBRID_MSD_BITS: test aid, the finer splits on inputs a checker can follow
+    if (const char* e = std::getenv("MRS_HYBRID_MSD_BITS")) {
+        const uint32_t forced = static_cast<uint32_t>(std::atoi(e));
+        if (forced >= 14 && forced <= 16) bits = forced;
+    }
+    if (bits + 16 < width) bits = width - 16;
+    return bits;
 }
 
 // The schedule of an MRS_ALGO_HYBRID plan (mrs_hybrid.hpp): both pass sequences are enqueued and the
@@ -756,14 +776,16 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     if (int rc = mark(plan, "memset", s)) return rc;
     const uint32_t begin_bit = plan->desc.begin_bit, end_bit = plan->desc.end_bit;
     const int hist_grid = hybrid_histogram_grid(plan->ctx->num_cus, n32);
-    if (int rc = hybrid_launch_histogram(static_cast<const uint32_t*>(keys_a), n32, end_bit - 16, hist_grid,
+    const uint32_t msd_bits = hybrid_msd_bits(plan, n32);
+    const uint32_t bits_a = (msd_bits + 1) / 2, bits_b = msd_bits - bits_a;  // 7 or 8 each
+    if (int rc = hybrid_launch_histogram(static_cast<const uint32_t*>(keys_a), n32, end_bit - msd_bits, msd_bits, hist_grid,
                                          plan->hyb_packed, plan->hyb_header, s))
         return rc;
     if (int rc = mark(plan, "msd_histogram", s)) return rc;
     // MRS_HYBRID_FORCE_FALLBACK: test aid, the device takes the plan's ordinary passes whatever the keys are
     const uint32_t force = std::getenv("MRS_HYBRID_FORCE_FALLBACK") ? kHybFallback : 0u;
     if (int rc = hybrid_launch_scan(plan->hyb_packed, hist_grid, plan->hyb_tables, plan->hyb_header, n32,
-                                    plan->tile_items, force, s))
+                                    plan->tile_items, force, bits_b, s))
         return rc;
     if (int rc = mark(plan, "msd_scan", s)) return rc;
     // the other schedule's digit histograms: counted only if the device chose it
@@ -793,7 +815,8 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     a.vals_in = vals_a;
     a.keys_out = keys_b;
     a.vals_out = vals_b;
-    a.shift = end_bit - 8;
+    a.shift = end_bit - bits_a;
+    a.mask = (1u << bits_a) - 1u;
     a.digit_base = plan->hyb_tables->bucket_start;
     a.status = plan->status;
     a.tile_counter = plan->control->tile_counter[kMaxPasses - 2];
@@ -807,7 +830,8 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     a.vals_in = vals_b;
     a.keys_out = keys_a;
     a.vals_out = vals_a;
-    a.shift = end_bit - 16;
+    a.shift = end_bit - msd_bits;
+    a.mask = (1u << bits_b) - 1u;
     a.digit_base = nullptr;
     a.status = plan->status + region;
     a.tile_counter = plan->control->tile_counter[kMaxPasses - 1];
@@ -818,10 +842,10 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
         return rc;
     if (int rc = mark(plan, "msd_pass_b", s)) return rc;
     // the remaining bits, inside LDS, in place
-    const uint32_t low_bits = end_bit - 16 - begin_bit;  // 9..16
+    const uint32_t low_bits = end_bit - msd_bits - begin_bit;  // 9..16
     const uint32_t bits1 = (low_bits + 1) / 2;
     if (int rc = hybrid_launch_local_sort(static_cast<uint32_t*>(keys_a), static_cast<uint32_t*>(vals_a), plan->hyb_header,
-                                          plan->hyb_tables, begin_bit, bits1, low_bits - bits1,
+                                          plan->hyb_tables, begin_bit, bits1, low_bits - bits1, 1u << msd_bits,
                                           hybrid_local_sort_grid(plan->ctx->num_cus), s))
         return rc;
     if (int rc = mark(plan, "msd_local_sort", s)) return rc;
@@ -890,7 +914,7 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
         if (int rc = launch_small_sort(plan->desc.key_words, plan->radix_bits, a, s)) return rc;
         return mark(plan, "small_sort", s);
     }
-    plan->hyb_last = plan->hybrid && !primed && n >= hybrid_min_n();
+    plan->hyb_last = plan->hybrid && !primed && n >= hybrid_min_n(plan);
     if (plan->hyb_last)
         return sort_pairs_hybrid(plan, n32, keys_a, vals_a, keys_b, vals_b, s, indexed);
     // 64-bit keys: passes whose digit is the same for every key are left out on the device

@@ -14,7 +14,7 @@ namespace mrs {
 // hdr->overflow, and the decision kernel then chooses the other schedule, which such an input
 // needs anyway.
 __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t n,
-                                                                 uint32_t vectors, uint32_t shift,
+                                                                 uint32_t vectors, uint32_t shift, uint32_t bits,
                                                                  uint32_t* __restrict__ packed, HybridHeader* hdr)
 {
     constexpr int THREADS = 1024, UNROLL = 4;
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
     __syncthreads();
     uint32_t mine = 0;
     auto count = [&](uint32_t k) {
-        const uint32_t b = __builtin_amdgcn_ubfe(k, shift, 16);
+        const uint32_t b = __builtin_amdgcn_ubfe(k, shift, bits);  // bits <= 16: counters beyond 2^bits stay zero
         atomicAdd(&s_cnt[b >> 1], 1u << ((b & 1u) * 16u));
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -103,10 +103,12 @@ __global__ __launch_bounds__(256) void hybrid_reduce_kernel(const uint32_t* __re
     reinterpret_cast<uint2*>(counts)[j] = make_uint2(lo, hi);
 }
 
-// One workgroup: exclusive scan of the 65536 counts (thread t owns entries 64t .. 64t+63, a
-// quarter of bucket t / 4), bucket starts, the tile table of pass B and the decision.
+// One workgroup: exclusive scan of the 65536 counts (thread t owns entries 64t .. 64t+63; a bucket
+// has 2^sub_bits >= 64 sub-buckets, so it starts with a thread), bucket starts, the tile table of
+// pass B and the decision.  Buckets and sub-buckets the split does not use are empty and start at n.
 __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, HybridHeader* hdr, uint32_t n,
-                                                            uint32_t tile_items, uint32_t cap, uint32_t force_mode)
+                                                            uint32_t tile_items, uint32_t cap, uint32_t force_mode,
+                                                            uint32_t sub_bits)
 {
     __shared__ uint32_t s_wsum[16];
     __shared__ uint32_t s_bstart[kHybBuckets + 1];
@@ -146,8 +148,11 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
     uint32_t run = incl - sum;
     for (uint32_t w = 0; w < 16; ++w)
         if (w < wave) run += s_wsum[w];
-    if ((tid & 3u) == 0) s_bstart[tid >> 2] = run;
-    if (tid == 1023) s_bstart[kHybBuckets] = run + sum;
+    // thread t starts bucket t >> (sub_bits - 6) if it starts one; the threads past the last bucket
+    // the split uses hold zeros, so the unused buckets start at n
+    const uint32_t tpb = sub_bits - 6u;  // log2(threads per bucket)
+    if ((tid & ((1u << tpb) - 1u)) == 0 && (tid >> tpb) <= kHybBuckets) s_bstart[tid >> tpb] = run;
+    if (tid == 1023 && (1024u >> tpb) <= kHybBuckets) s_bstart[1024u >> tpb] = run + sum;  // sub_bits == 8: no thread starts "bucket 256"
     {
         uint4* o4 = reinterpret_cast<uint4*>(tb->sub_start) + tid * 16;
 #pragma unroll
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
             const uint32_t base = start + (tile - first) * static_cast<uint32_t>(S::TILE);
             const uint32_t remaining = end - base;
             PassArgs b = a;
-            b.digit_base = tb->sub_start + seg * 256u;
+            b.digit_base = tb->sub_start + seg * (a.mask + 1u);  // the bucket's sub-buckets, a.mask + 1 of them
             if (remaining >= static_cast<uint32_t>(S::TILE))
                 process_tile<kModeOnesweep, kRankAtomic, kMapNone, true, uint32_t>(b, sh, tile, S::TILE, base, first);
             else
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
                                                                      const HybridHeader* __restrict__ hdr,
                                                                      const HybridTables* __restrict__ tb,
                                                                      const uint32_t shift, const uint32_t bits1,
-                                                                     const uint32_t bits2)
+                                                                     const uint32_t bits2, const uint32_t num_subs)
 {
     constexpr int WAVES = THREADS / 64;
     constexpr int RADIX = 256;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
     __shared__ uint32_t s_hist[2][WAVES][RADIX];
     __shared__ uint32_t s_wsum[2][4];
     __shared__ uint32_t s_first[kLocalMaxPerGroup], s_count[kLocalMaxPerGroup];
-    if (hdr->mode != kHybRun || blockIdx.x >= kHybSubs) return;  // uniform
+    if (hdr->mode != kHybRun || blockIdx.x >= num_subs) return;  // uniform
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t shifts[2] = {shift, shift + bits1};
     const uint32_t widths[2] = {bits1, bits2};
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
     // (a scalar load inside the loop would be waited for at the next LDS access).  Two register
     // sets take turns: while one sub-bucket is sorted and written out, the pairs of the next are
     // already on their way into the other set, so the workgroup always has loads in flight.
-    const uint32_t mine = (kHybSubs - 1u - blockIdx.x) / gridDim.x + 1u;  // blockIdx.x < kHybSubs
+    const uint32_t mine = (num_subs - 1u - blockIdx.x) / gridDim.x + 1u;  // blockIdx.x < num_subs <= kHybSubs
     for (uint32_t j = tid; j < mine; j += THREADS) {
         const uint32_t which = blockIdx.x + j * gridDim.x;
         s_first[j] = tb->sub_start[which];
@@ -437,21 +442,22 @@ int hybrid_local_sort_grid(int num_cus)
     return g < static_cast<int>(kLocalMinGrid) ? static_cast<int>(kLocalMinGrid) : g;
 }  // 80 KiB of LDS each: two per compute unit
 
-int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, int grid, uint32_t* packed,
+int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t bits, int grid, uint32_t* packed,
                             HybridHeader* hdr, hipStream_t s)
 {
     const uint32_t vectors = (reinterpret_cast<uintptr_t>(keys) & 15u) ? 0u : n / 4u;
-    hipLaunchKernelGGL(hybrid_histogram_kernel, dim3(grid), dim3(1024), 0, s, keys, n, vectors, shift, packed, hdr);
+    hipLaunchKernelGGL(hybrid_histogram_kernel, dim3(grid), dim3(1024), 0, s, keys, n, vectors, shift, bits, packed, hdr);
     MRS_CHECK_LAUNCH("hybrid_histogram_kernel");
     return MRS_OK;
 }
 
 int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridHeader* hdr, uint32_t n,
-                       uint32_t tile_items, uint32_t force_mode, hipStream_t s)
+                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, hipStream_t s)
 {
+    if (sub_bits < 6 || sub_bits > 8) return fail(MRS_ERR_UNSUPPORTED, "a bucket has 64 to 256 sub-buckets");
     hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(kHybPackedWords / 256), dim3(256), 0, s, packed, grid, tables->counts);
     MRS_CHECK_LAUNCH("hybrid_reduce_kernel");
-    hipLaunchKernelGGL(hybrid_scan_kernel, dim3(1), dim3(1024), 0, s, tables, hdr, n, tile_items, kHybLocalCap, force_mode);
+    hipLaunchKernelGGL(hybrid_scan_kernel, dim3(1), dim3(1024), 0, s, tables, hdr, n, tile_items, kHybLocalCap, force_mode, sub_bits);
     MRS_CHECK_LAUNCH("hybrid_scan_kernel");
     return MRS_OK;
 }
@@ -483,12 +489,13 @@ int hybrid_launch_pass(bool segmented, bool persistent, int threads, int kpt, co
 }
 
 int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,
-                             uint32_t shift, uint32_t bits1, uint32_t bits2, int grid, hipStream_t s)
+                             uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, int grid, hipStream_t s)
 {
+    if (num_subs == 0 || num_subs > kHybSubs) return fail(MRS_ERR_UNSUPPORTED, "at most 65536 sub-buckets");
     if (bits1 == 0 || bits1 > 8 || bits2 == 0 || bits2 > 8)
         return fail(MRS_ERR_UNSUPPORTED, "the local sort takes two digits of 1 to 8 bits");
     hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreads, kHybLocalKpt>), dim3(grid), dim3(kHybLocalThreads), 0, s,
-                       keys, vals, hdr, tables, shift, bits1, bits2);
+                       keys, vals, hdr, tables, shift, bits1, bits2, num_subs);
     MRS_CHECK_LAUNCH("hybrid_local_sort_kernel");
     return MRS_OK;
 }

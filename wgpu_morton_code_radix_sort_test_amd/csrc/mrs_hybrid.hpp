@@ -4,11 +4,13 @@
 // The reference sorts least significant digit first, NUM_PASSES scatters of the whole array
 // (src/main.rs:594-665).  A stable sort has one answer, so any schedule that is stable gives the
 // same bytes; this one moves every pair three times instead of four:
-//   pass A  one chained-scan scatter by the top 8 of the sorted bits (256 buckets);
-//   pass B  one chained-scan scatter by the next 8 bits, every bucket a chain of its own
-//           (65536 sub-buckets; tiles never straddle a bucket);
+//   pass A  one chained-scan scatter by the top 7 or 8 of the sorted bits (128 or 256 buckets);
+//   pass B  one chained-scan scatter by the next 7 or 8 bits, every bucket a chain of its own
+//           (2^14 to 2^16 sub-buckets; tiles never straddle a bucket);
 //   local   every sub-bucket is loaded into LDS by one workgroup, sorted there by the remaining
 //           9..16 bits in two stable counting passes, and written back in place, sequentially.
+// The split (14, 15 or 16 bits for A and B together) is the host's, from n: sub-buckets of about
+// 4096 pairs keep the local sort's workgroups busy, and the local sort takes at most 16 bits.
 // It needs sub-buckets that fit a workgroup, which only the device can know (the host never reads
 // a key), so a 16-bit histogram taken before pass A decides on the device: if any sub-bucket
 // exceeds the capacity, the three kernels above return at once and the four least-significant-
@@ -21,8 +23,8 @@
 
 namespace mrs {
 
-constexpr uint32_t kHybBuckets = 256;   // first level: the top 8 of the sorted bits
-constexpr uint32_t kHybSubs = 65536;    // second level: the top 16
+constexpr uint32_t kHybBuckets = 256;   // first level, at most: the top 8 of the sorted bits
+constexpr uint32_t kHybSubs = 65536;    // second level, at most: the top 16
 constexpr uint32_t kHybRun = 1;         // HybridHeader::mode: the three-move schedule runs
 constexpr uint32_t kHybFallback = 2;    // the plan's least-significant-digit-first passes run
 constexpr int kHybLocalThreads = 512;   // workgroup of the local sort
@@ -54,12 +56,12 @@ size_t hybrid_packed_bytes(int grid);
 int hybrid_histogram_grid(int num_cus, uint64_t n);
 int hybrid_local_sort_grid(int num_cus);
 
-// 16-bit histogram of (key >> shift) & 0xFFFF: one packed table per workgroup.
-int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, int grid, uint32_t* packed,
+// Histogram of the `bits` <= 16 key bits from `shift` up: one packed table per workgroup.
+int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t bits, int grid, uint32_t* packed,
                             HybridHeader* hdr, hipStream_t s);
 // Sum of the `grid` packed tables, its exclusive scan, the tile table of pass B and the decision.
 int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridHeader* hdr, uint32_t n,
-                       uint32_t tile_items, uint32_t force_mode, hipStream_t s);
+                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, hipStream_t s);
 // One chained-scan pass that runs only if hdr->mode == run_if_mode.  segmented: pass B (tiles and
 // chains per bucket, a.digit_base and a.num_tiles ignored); otherwise a pass over the whole array.
 // persistent: `grid` workgroups draw tiles until none is left (an idle launch then costs `grid`
@@ -69,7 +71,7 @@ int hybrid_launch_pass(bool segmented, bool persistent, int threads, int kpt, co
                        hipStream_t s);
 // Sorts every sub-bucket in place on bits [shift, shift + bits1 + bits2).
 int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,
-                             uint32_t shift, uint32_t bits1, uint32_t bits2, int grid, hipStream_t s);
+                             uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, int grid, hipStream_t s);
 
 }  // namespace mrs
 
