@@ -35,6 +35,53 @@ def pick(d, needle):
     return None
 
 
+def summarize_hybrid(args, n, library_rows):
+    """Kernel statistics and per-launch HBM traffic of the MRS_ALGO_HYBRID schedule's kernels."""
+    root = os.path.join(ROOT, args.hybrid_root)
+    for d in sorted(glob.glob(os.path.join(root, "prof_*"))):
+        if not os.path.isdir(d):
+            continue
+        name = os.path.basename(d)[len("prof_"):]
+        for path in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+            with open(os.path.join(ROOT, "profiles", f"{args.tag}_{name}_kernel_stats.csv"), "w", newline="") as f:
+                csv.writer(f).writerows(library_rows(path))
+    fetch = counter_means(os.path.join(root, "pmc_fetch", "**", "*counter_collection.csv"), "FETCH_SIZE")
+    write = counter_means(os.path.join(root, "pmc_write", "**", "*counter_collection.csv"), "WRITE_SIZE")
+    if not fetch or not write:
+        return
+    cal_enc = 12.0 * n / (pick(fetch, "morton_encode30") * 1024.0)
+    cal_hist = 4.0 * n / (pick(fetch, "hybrid_histogram_kernel") * 1024.0)
+    cal_w = 8.0 * n / (pick(write, "morton_encode30") * 1024.0)
+    factor = 0.5 * (cal_enc + cal_hist)
+
+    def traffic(needle):
+        f, w = pick(fetch, needle), pick(write, needle)
+        return {"read_bytes_per_launch": f * 1024.0 * factor, "write_bytes_per_launch": w * 1024.0 * cal_w,
+                "bytes_per_launch": f * 1024.0 * factor + w * 1024.0 * cal_w, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w}
+
+    a, b = traffic("hybrid_pass_kernel<false, false"), traffic("hybrid_pass_kernel<true, false")
+    entry = {
+        "kernel": "hybrid_pass_kernel (mean of pass A and pass B)",
+        "n": n,
+        "bytes_per_launch": 0.5 * (a["bytes_per_launch"] + b["bytes_per_launch"]),
+        "algorithmic_bytes_per_launch": 16.0 * n,
+        "pass_a": a,
+        "pass_b": b,
+        "local_sort": traffic("hybrid_local_sort_kernel"),
+        "histogram": traffic("hybrid_histogram_kernel"),
+        "fetch_calibration": {"morton_encode30 (12 B/point)": cal_enc, "hybrid_histogram (4 B/key)": cal_hist, "applied": factor},
+        "write_calibration": {"morton_encode30 (8 B/point)": cal_w},
+        "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs of tools/sort_once.py --algo hybrid --end-bit 30",
+        "measured": args.measured,
+    }
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    whole = json.load(open(path)) if os.path.exists(path) else {}
+    whole["hybrid_pass"] = entry
+    with open(path, "w") as f:
+        json.dump(whole, f, indent=1)
+    print(json.dumps(entry, indent=1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="r01")
@@ -46,6 +93,9 @@ def main():
                                                "prof_NAME below it becomes profiles/TAG_NAME_kernel_stats.csv, and its "
                                                "pmc_fetch / pmc_write feed traffic.json")
     ap.add_argument("--measured", default="", help="free text stored in traffic.json (date, commit)")
+    ap.add_argument("--hybrid-root", default="", help="directory written by tools/collect_hybrid_profiles.sh: its prof_NAME "
+                                                      "become profiles/TAG_NAME_kernel_stats.csv and its pmc_fetch / pmc_write "
+                                                      "the `hybrid_pass` entry of traffic.json (the rest of the file is kept)")
     args = ap.parse_args()
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     n = 1 << args.log2n
@@ -69,6 +119,10 @@ def main():
         for path in glob.glob(os.path.join(ROOT, args.stats_dir, "**", "*kernel_stats.csv"), recursive=True):
             with open(os.path.join(ROOT, "profiles", f"{args.tag}_kernel_stats.csv"), "w", newline="") as f:
                 csv.writer(f).writerows(library_rows(path))
+
+    if args.hybrid_root:
+        summarize_hybrid(args, n, library_rows)
+        return
 
     fetch = counter_means(os.path.join(ROOT, args.fetch_dir, "**", "*counter_collection.csv"), "FETCH_SIZE")
     write = counter_means(os.path.join(ROOT, args.write_dir, "**", "*counter_collection.csv"), "WRITE_SIZE")
