@@ -69,6 +69,49 @@ def test_full_size_sort_properties(ctx, mrs, log2n, algo_name, bits):
     plan.close()
 
 
+@pytest.mark.parametrize("log2n,end_bit,want", [(28, 30, "msd"), (28, 32, "refused"), (27, 30, "msd"), (26, 30, "msd"),
+                                                (26, 32, "passes")])
+def test_full_size_hybrid_plan_equals_four_passes(ctx, mrs, log2n, end_bit, want):
+    """MRS_ALGO_HYBRID plans at the sizes they exist for, against the four-pass plan on the same
+    input, pair for pair (a stable sort has one answer), plus the size-independent properties.
+    30-bit codes declared as 32-bit keys leave three quarters of the leading buckets empty: the
+    device refuses and the result is still that of the four passes; 2^26 pairs of 32-bit keys are
+    below the size the three-move schedule pays for, and the host does not enqueue it."""
+    n = 1 << log2n
+    xyz = ctx.generate_points(23, n)
+    keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+    del xyz
+    keys_in = keys.clone()
+    kb, vb = torch.empty_like(keys), torch.empty_like(idx)
+    ref = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, end_bit=end_bit, algo=mrs.ALGO_ONESWEEP)
+    rk, rv = keys.clone(), idx.clone()
+    assert not ref.sort_pairs(rk, rv, kb, vb)
+    ref.check()
+    ref.close()
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, end_bit=end_bit, algo=mrs.ALGO_HYBRID)
+    assert not plan.sort_pairs(keys, idx, kb, vb)
+    plan.check()
+    schedule, largest = plan.schedule()
+    assert schedule == {"msd": plan.SCHEDULE_MSD, "refused": plan.SCHEDULE_MSD_REFUSED, "passes": plan.SCHEDULE_PASSES}[want], largest
+    assert bool((keys == rk).all()) and bool((idx == rv).all())
+    check_sorted_pairs(keys, idx, keys_in)
+    # the sort that makes the indices up, and a second call on the plan
+    keys.copy_(keys_in)
+    idx.fill_(-1)
+    assert not plan.sort_pairs_indexed(keys, idx, kb, vb)
+    plan.check()
+    assert bool((keys == rk).all()) and bool((idx == rv).all())
+    # all-equal keys at this size: one sub-bucket holds everything, the device takes the four passes
+    keys.fill_(0x155A5A5A)
+    idx.copy_(torch.arange(n, dtype=torch.int32, device=ctx.device))
+    plan.sort_pairs(keys, idx, kb, vb)
+    plan.check()
+    if want != "passes":
+        assert plan.schedule()[0] == plan.SCHEDULE_MSD_REFUSED
+    assert bool((idx == torch.arange(n, dtype=torch.int32, device=ctx.device)).all())
+    plan.close()
+
+
 @pytest.mark.parametrize("payload_words", [1, 4])
 def test_large_u64_keys_properties(ctx, mrs, payload_words):
     """64-bit keys (the reference's code type) with an index or a 16-byte TriangleIndices-sized
