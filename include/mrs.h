@@ -156,7 +156,8 @@ int mrs_plan_get_passes_left_out(mrs_plan* plan, void* stream, uint32_t* left_ou
  * other schedule), MRS_SCHEDULE_MSD (an MRS_ALGO_HYBRID plan whose keys the device found spread
  * well enough) or MRS_SCHEDULE_MSD_REFUSED (the device found a sub-bucket too large and ran the
  * ordinary passes).  *largest_sub_bucket (may be NULL) receives the size of the largest of the
- * 65536 sub-buckets the device counted, 0 when it counted none.  For tests and harnesses; the
+ * sub-buckets the device counted, 0 when it counted none, 0xFFFFFFFF when it stopped counting
+ * because one workgroup's share of a sub-bucket alone was too large.  For tests and harnesses; the
  * reference always runs its one schedule (src/main.rs:594-665). */
 #define MRS_SCHEDULE_PASSES 0
 #define MRS_SCHEDULE_MSD 1

@@ -12,25 +12,42 @@ namespace mrs {
 // wraps (65536 keys of one workgroup in one sub-bucket) loses 65535 or 65536 from the sum of the
 // fields, never gains: a workgroup whose fields do not add up to the keys it counted raises
 // hdr->overflow, and the decision kernel then chooses the other schedule, which such an input
-// needs anyway.
+// needs anyway.  The atomics return the old word: a lane that finds more than `cap` keys already
+// counted in its field knows that the sub-bucket is too large whatever the other workgroups hold,
+// raises the flag and lets the workgroup stop (equal or few distinct keys would otherwise queue
+// 64 lanes on one word for the whole input: 0.9 ms instead of 0.17 at 2^28).
 __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                  uint32_t vectors, uint32_t shift, uint32_t bits,
-                                                                 uint32_t* __restrict__ packed, HybridHeader* hdr)
+                                                                 uint32_t* __restrict__ packed, HybridHeader* hdr,
+                                                                 uint32_t cap)
 {
     constexpr int THREADS = 1024, UNROLL = 4;
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kHybPackedWords];
     __shared__ int s_diff;
+    __shared__ uint32_t s_stop;
     const uint32_t tid = threadIdx.x;
     {
         uint4* z = reinterpret_cast<uint4*>(s_cnt);
         for (uint32_t j = tid; j < kHybPackedWords / 4; j += THREADS) z[j] = make_uint4(0, 0, 0, 0);
     }
-    if (tid == 0) s_diff = 0;
+    if (tid == 0) {
+        s_diff = 0;
+        s_stop = 0;
+    }
     __syncthreads();
     uint32_t mine = 0;
+    uint32_t most = 0;  // largest count this lane has seen in a field before its own increment
     auto count = [&](uint32_t k) {
         const uint32_t b = __builtin_amdgcn_ubfe(k, shift, bits);  // bits <= 16: counters beyond 2^bits stay zero
-        atomicAdd(&s_cnt[b >> 1], 1u << ((b & 1u) * 16u));
+        const uint32_t half = (b & 1u) * 16u;
+        const uint32_t old = atomicAdd(&s_cnt[b >> 1], 1u << half);
+        const uint32_t seen = (old >> half) & 0xFFFFu;
+        most = seen > most ? seen : most;
+    };
+    // uniform for the wave; the other waves learn of it from LDS at their next step
+    auto too_many = [&]() {
+        if (__builtin_amdgcn_uicmp(most, cap, 35 /* >= */) != 0ull) s_stop = 1;
+        return s_stop != 0;
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4* __restrict__ vkeys = reinterpret_cast<const u32x4*>(keys);
@@ -46,8 +63,9 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
             count(x[u].x); count(x[u].y); count(x[u].z); count(x[u].w);
         }
         mine += 4 * UNROLL;
+        if (too_many()) break;
     }
-    for (; v < vectors; v += stride) {
+    for (; v < vectors && s_stop == 0; v += stride) {
         const u32x4 x = __builtin_nontemporal_load(vkeys + v);
         count(x.x); count(x.y); count(x.z); count(x.w);
         mine += 4;
@@ -58,6 +76,10 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
         mine += 1;
     }
     __syncthreads();
+    if (s_stop != 0) {  // uniform: the counts are incomplete and nobody will read them
+        if (tid == 0) atomicOr(&hdr->overflow, 1u);
+        return;
+    }
     uint32_t fields = 0;
     {
         const uint4* c = reinterpret_cast<const uint4*>(s_cnt);
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
             const bool ok = s_max <= cap && hdr->overflow == 0 && s_bstart[kHybBuckets] == n && force_mode != kHybFallback;
             tb->first_tile[kHybBuckets] = total_tiles;
             hdr->num_tiles_b = ok ? total_tiles : 0u;
-            hdr->max_sub = s_max;
+            hdr->max_sub = hdr->overflow ? 0xFFFFFFFFu : s_max;  // a histogram that stopped early has no counts to report
             hdr->mode = ok ? kHybRun : kHybFallback;
         }
     }
@@ -242,17 +264,23 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
         }
     }
     for (;;) {
+        // The gate word and the first ticket travel together: a workgroup of a launch that runs
+        // does not wait for one after the other, and one of a launch that is switched off leaves
+        // as soon as the word is there (having wasted a ticket of a counter nobody else reads).
+        Ticket ticket{0, 0};
+        if (tid == 0) ticket = ticket_issue(a);
+        if (mode != run_if_mode) return;  // uniform
         if (tid == 0) {
-            // the gate word and the ticket travel together; a launch that is switched off
-            // wastes one ticket of a counter nobody else reads
-            const uint32_t t = draw_tile(a, num_tiles);
-            sh.tile = mode == run_if_mode ? t : 0xFFFFFFFFu;
+            sh.tile = ticket_tile(a, ticket, num_tiles);
             sh.abort = 0;
         }
-        for (int j = tid; j < S::WAVES * S::RADIX; j += THREADS) (&sh.wave_hist[0][0])[j] = 0;
         __syncthreads();
         const uint32_t tile = sh.tile;
         if (tile >= num_tiles) return;  // uniform
+        // Ranking touches only the wave's own counters, so each wave clears its own row and no
+        // barrier is needed before the ranking (the rows are read across waves after its barrier);
+        // a workgroup without a tile has left by now.
+        for (int j = tid & 63; j < S::RADIX; j += 64) sh.wave_hist[tid >> 6][j] = 0;
         if constexpr (SEG) {
             if (tid < kHybBuckets && ft0 <= tile && tile < ft1) {  // exactly one thread: empty buckets have ft0 == ft1
                 s_seg[0] = tid;
@@ -459,7 +487,8 @@ int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, ui
                             HybridHeader* hdr, hipStream_t s)
 {
     const uint32_t vectors = (reinterpret_cast<uintptr_t>(keys) & 15u) ? 0u : n / 4u;
-    hipLaunchKernelGGL(hybrid_histogram_kernel, dim3(grid), dim3(1024), 0, s, keys, n, vectors, shift, bits, packed, hdr);
+    hipLaunchKernelGGL(hybrid_histogram_kernel, dim3(grid), dim3(1024), 0, s, keys, n, vectors, shift, bits, packed, hdr,
+                       kHybLocalCap);
     MRS_CHECK_LAUNCH("hybrid_histogram_kernel");
     return MRS_OK;
 }

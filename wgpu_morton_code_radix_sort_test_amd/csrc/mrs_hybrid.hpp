@@ -37,7 +37,7 @@ struct HybridHeader {
     uint32_t mode;         // 0 until hybrid_scan_kernel has decided
     uint32_t num_tiles_b;  // tiles of pass B (0 unless mode == kHybRun)
     uint32_t overflow;     // a 16-bit counter of the histogram wrapped: counts are not to be trusted
-    uint32_t max_sub;      // largest sub-bucket (diagnostic)
+    uint32_t max_sub;      // largest sub-bucket (diagnostic); 0xFFFFFFFF if the histogram stopped early or wrapped
     uint32_t pad[60];
 };
 static_assert(sizeof(HybridHeader) == 256, "the header takes one 256-byte slot of the cleared block");

@@ -745,7 +745,7 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
 // Tile id of a workgroup.  With xcd_block = B > 0 the tiles are dealt in blocks of B
 // consecutive tiles, block g to die g % 8: a workgroup draws from the list of the die it runs
 // on (hardware register XCC_ID), and from the other lists once its own is exhausted.  Every
-// list is drawn in ascending order and there are exactly as many workgroups as tiles, so the
+// list is drawn in ascending order and there are at least as many workgroups as tiles, so the
 // lowest unfinished tile is either held by a running workgroup or the next to be drawn ON ITS
 // DIE: the look-back makes progress as long as this kernel keeps getting workgroup slots on
 // every die, which holds when it has the device to itself or shares it with kernels that end on
@@ -754,22 +754,41 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
 // mrs_api.hip) and a wait that does starve ends in the time-out of the look-back, not in a hang.
 // With B = 0 there is one list: drawn tiles are always a prefix, the lowest unfinished tile is
 // always running, and one free slot anywhere is enough.
+//
+// The draw in two steps, for callers that have something to wait for in between: ticket_issue
+// sends the atomic of the first list (the die's own, or the only one), ticket_tile turns what it
+// returned into a tile and goes on to the other dies' lists if that list is exhausted.
 // `num_tiles`: tiles of this pass (a.num_tiles, or a count only the device knows).
-__device__ __forceinline__ uint32_t draw_tile(const PassArgs& a, const uint32_t num_tiles)
+struct Ticket {
+    uint32_t k;     // what the first list's counter held
+    uint32_t list;  // which list that was
+};
+__device__ __forceinline__ Ticket ticket_issue(const PassArgs& a)
+{
+    Ticket t;
+    t.list = 0;
+    if (a.xcd_block != 0) {
+        // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
+        t.list = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (kTicketLists - 1);
+    }
+    t.k = atomicAdd(a.tile_counter + t.list, 1u);
+    return t;
+}
+__device__ __forceinline__ uint32_t ticket_tile(const PassArgs& a, const Ticket first, const uint32_t num_tiles)
 {
     const uint32_t B = a.xcd_block;
-    if (B == 0) return atomicAdd(a.tile_counter, 1u);
-    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
-    const uint32_t die = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (kTicketLists - 1);
-    for (uint32_t i = 0; i < kTicketLists; ++i) {
-        const uint32_t list = (die + i) & (kTicketLists - 1);
-        const uint32_t k = atomicAdd(a.tile_counter + list, 1u);
+    if (B == 0) return first.k;
+    uint32_t k = first.k, list = first.list;
+    for (uint32_t i = 0;;) {
         const unsigned long long tile = (static_cast<unsigned long long>(k / B) * kTicketLists + list) * B + k % B;
         if (tile < num_tiles) return static_cast<uint32_t>(tile);
+        if (++i == kTicketLists) break;
+        list = (first.list + i) & (kTicketLists - 1);
+        k = atomicAdd(a.tile_counter + list, 1u);
     }
     return num_tiles;  // only with more workgroups than tiles
 }
-__device__ __forceinline__ uint32_t draw_tile(const PassArgs& a) { return draw_tile(a, a.num_tiles); }
+__device__ __forceinline__ uint32_t draw_tile(const PassArgs& a) { return ticket_tile(a, ticket_issue(a), a.num_tiles); }
 
 // The scatter of the three-kernel pass has no chain, so any one-to-one map from workgroup to
 // tile will do.  Workgroups are dealt to the 8 dies round robin by index; this map gives the 8
