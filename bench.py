@@ -389,7 +389,7 @@ def main():
             achieved = PASS_BYTES_PER_PAIR * sorter.n_out / avg_pass / 1e9
             roofline = {
                 "bound": "hbm",
-                "kernel": "digit_pass_kernel<onesweep> (local sort of rank 0)",
+                "kernel": "the chained-scan digit pass (local sort of rank 0: " + ", ".join(breakdown.get("dist_local_sort_schedule", [])) + ")",
                 "achieved": achieved,
                 "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                 "unit": "GB/s",
@@ -446,7 +446,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"2^{args.log2n} (30-bit Morton key, u32 index) pairs per GPU from uniform random 3D points, "
-                            + (f"8-bit digits over key bits [0, 30), onesweep local sorts" if distributed else
+                            + (f"key bits [0, 30), local sorts by the three-move schedule over each piece's window of the key space (four 8-bit passes where the device refuses it)" if distributed else
                                f"{args.digit_bits}-bit digits over key bits [0, {end_bit}), {args.algo}"),
                 "pairs_per_gpu": n,
                 "total_pairs": total_pairs,

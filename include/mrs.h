@@ -330,7 +330,9 @@ int mrs_partition(mrs_plan* plan, uint64_t n, const void* keys_in, const void* v
  *   4. one stable partition pass by destination (the chained-scan pass with a bucket table);
  *   5. grouped ncclSend/ncclRecv of keys and payload (all-to-all-v over xGMI), received in source
  *      rank order;
- *   6. local sort of what arrived (mrs_sort_pairs).
+ *   6. local sort of what arrived (mrs_sort_pairs; for (u32 key, u32 payload) pairs an
+ *      MRS_ALGO_HYBRID plan whose sub-buckets divide the slice's own window of the key space, the
+ *      cut keys on either side of it, once a piece holds 2^26 pairs).
  * All device work is enqueued on the caller's stream. */
 typedef struct mrs_comm mrs_comm;
 typedef struct mrs_dist mrs_dist;
@@ -373,6 +375,8 @@ typedef struct mrs_dist_info {
     float last_sort_pass_ms;  /* last call with timing on: mean duration of one digit pass of the
                                  local sort (HIP events on the launch stream)                      */
     uint32_t last_sort_passes;
+    uint32_t last_sort_schedule[2]; /* MRS_SCHEDULE_* of the local sort of each piece of the last call
+                                       (mrs_dist_get_info waits for the device to read them)            */
 } mrs_dist_info;
 
 int mrs_dist_create(mrs_context* ctx, mrs_comm* comm, const mrs_dist_desc* desc, mrs_dist** out);

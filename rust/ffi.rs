@@ -50,6 +50,7 @@ pub struct mrs_dist_info {
     pub last_ms: [f32; 4],
     pub last_sort_pass_ms: f32,
     pub last_sort_passes: u32,
+    pub last_sort_schedule: [u32; 2],
 }
 
 #[repr(C)]

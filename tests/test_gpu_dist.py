@@ -157,6 +157,42 @@ def test_local_ranks_match_one_stable_sort(oracle, mrs, world, key_words, end_bi
         assert all(i.last_levels == 1 and i.last_exact_cuts == 0 for i in infos)
 
 
+WINDOW_CASES = [
+    # world, end_bit, distribution, pieces per rank, schedule every local sort must report (None: any)
+    (2, 30, "morton30", 0, "msd"),
+    (2, 30, "morton30", 1, "msd"),
+    (3, 32, "random", 0, None),      # one rank is empty, one tiny: their pieces differ
+    (8, 30, "morton30", 0, "msd"),
+    (4, 32, "sorted", 2, None),
+    (8, 32, "all_equal", 0, None),       # a piece of equal keys fits one sub-bucket at this size
+    (8, 32, "hot_bucket", 0, None),
+    (5, 32, "few_values", 0, None),
+    (16, 32, "random", 0, "msd"),
+    (1, 32, "random", 0, "msd"),
+]
+
+
+@pytest.mark.parametrize("world,end_bit,dist,chunks,want", WINDOW_CASES)
+def test_local_sorts_take_the_three_move_schedule(oracle, mrs, monkeypatch, world, end_bit, dist, chunks, want):
+    """The local sorts of (u32 key, u32 payload) slices are MRS_ALGO_HYBRID plans whose sub-buckets
+    divide the slice's window of the key space (the cut keys on either side).  The library keeps
+    pieces below 2^26 pairs on the ordinary passes, so the test lowers that threshold; the result
+    must be the one stable sort of the concatenated input whatever the device decides per piece."""
+    monkeypatch.setenv("MRS_HYBRID_MIN_N", "1")
+    rng = np.random.default_rng(world * 11 + end_bit)
+    sizes = [int(rng.integers(30000, 120000)) for _ in range(world)]
+    if world == 3:
+        sizes[1] = 0
+        sizes[2] = 4097
+    host_keys = [rank_keys(oracle, n, 1, dist, seed=17 * r + 3, end_bit=end_bit) for r, n in enumerate(sizes)]
+    results, infos = run_ranks(mrs, world, sizes, host_keys, 1, end_bit, 0, chunks=chunks)
+    check_against_oracle(oracle, results, host_keys, sizes, 1, end_bit, max(sizes) // 256)
+    pieces = chunks or (2 if 2 <= world <= 8 else 1)
+    seen = {int(i.last_sort_schedule[c]) for i in infos for c in range(pieces)}
+    if want == "msd":
+        assert seen == {1}, seen
+
+
 def test_local_ranks_fuzz(oracle, mrs):
     """Seeded random shapes of the sharded sort: rank count, slice sizes (empty and tiny slices
     included), key width and live bits, distribution, tolerance and pieces per rank drawn together.

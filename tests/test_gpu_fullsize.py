@@ -208,7 +208,8 @@ def test_sharded_sort_one_rccl_rank_full_size(ctx, mrs, dist_name):
 
 
 @pytest.mark.parametrize("world,log2n,dist_name", [(2, 26, "morton30"), (2, 26, "all_equal"), (2, 26, "one_hot_bucket"),
-                                                   (8, 24, "morton30"), (8, 24, "one_hot_bucket")])
+                                                   (8, 24, "morton30"), (8, 24, "one_hot_bucket"),
+                                                   (2, 27, "morton30"), (2, 27, "all_equal"), (2, 27, "one_hot_bucket")])
 def test_sharded_sort_ranks_on_one_gpu_large(ctx, mrs, world, log2n, dist_name):
     """In-process ranks share the GPU, two of 2^26 pairs each and eight of 2^24 (the rank count of
     the 8-GPU configuration: 16 destination pieces in the partition pass): the partition pass, the
@@ -269,3 +270,12 @@ def test_sharded_sort_ranks_on_one_gpu_large(ctx, mrs, world, log2n, dist_name):
         assert all(o[2].last_exact_cuts == 2 * world - 1 for o in outs) and outs[0][0].numel() == n
     if dist_name == "one_hot_bucket":
         assert all(o[2].last_levels >= 2 for o in outs)
+    if log2n >= 27:
+        # pieces of 2^26 pairs: the local sorts are offered the three-move schedule over the piece's
+        # window of the key space; spread keys take it, equal keys make the device refuse
+        # (a piece between two equal cut keys is not even offered it: 0; one next to the end of the key
+        # space has a wide window, is offered it, and the device refuses: 2)
+        want = {"morton30": (1,), "all_equal": (0, 2)}.get(dist_name)
+        if want is not None:
+            assert all(int(o[2].last_sort_schedule[c]) in want for o in outs for c in range(2)), \
+                [list(o[2].last_sort_schedule) for o in outs]

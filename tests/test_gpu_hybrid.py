@@ -1,6 +1,8 @@
 """GPU parity tests of MRS_ALGO_HYBRID plans: the most-significant-digit-first schedule and the
 ordinary passes the device falls back to, through the C ABI, bit for bit against the CPU checker's
 stable sort (a stable sort has one answer, whatever the order of its passes)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -90,7 +92,8 @@ def test_sub_buckets_at_the_capacity(ctx, oracle, mrs, small_inputs_take_the_sch
         vals = make_vals(oracle, n, 1)
         ko, vo, _, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 0, 32)
         rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
-        assert largest == size
+        # a histogram workgroup that finds the 7681st key of a sub-bucket in its own share stops counting
+        assert largest == size or (want == "refused" and largest == 0xFFFFFFFF)
         assert schedule == (mrs.SortPlan.SCHEDULE_MSD if want == "msd" else mrs.SortPlan.SCHEDULE_MSD_REFUSED)
         assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
 
@@ -225,8 +228,9 @@ def test_unsupported_shapes_are_refused(ctx, mrs):
 
 def test_fuzz(ctx, oracle, mrs, small_inputs_take_the_schedule):
     """Seeded random sizes, bit ranges, distributions and payload modes on hybrid plans."""
-    rng = np.random.RandomState(20241112)
-    for case in range(40):
+    seed = int(os.environ.get("MRS_FUZZ_SEED", "20241112"))
+    rng = np.random.RandomState(seed)
+    for case in range(int(os.environ.get("MRS_FUZZ_CASES", "40"))):
         n = int(rng.choice([rng.randint(4097, 9000), rng.randint(9000, 70000), rng.randint(70000, 500000)]))
         width = int(rng.randint(25, 33))
         begin = int(rng.randint(0, 32 - width + 1))
@@ -235,6 +239,13 @@ def test_fuzz(ctx, oracle, mrs, small_inputs_take_the_schedule):
         indexed = bool(rng.randint(2))
         tile = int(rng.choice([0, 4096, 32768]))
         keys = make_keys(oracle, n, 1, dist, seed=case)
+        if rng.randint(3) == 0:
+            # some sub-buckets near the capacity of a workgroup (7680 pairs), some beyond it
+            hot = int(rng.choice([7000, 7679, 7680, 7681, 9000]))
+            if hot < n:
+                at = rng.choice(n, size=hot, replace=False)
+                low = end - (16 if width > 30 else 14) - begin
+                keys[at] = (keys[at[0]] & ~np.uint32(((1 << low) - 1) << begin)) | ((keys[at] >> np.uint32(begin) & np.uint32((1 << low) - 1)) << np.uint32(begin))
         vals = np.arange(n, dtype=np.uint32) if indexed else make_vals(oracle, n, 1)
         ko, vo, in_b, schedule, _ = _sort_with_plan(ctx, mrs, keys, vals, n, begin, end, tile_items=tile, indexed=indexed)
         rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, begin, end)

@@ -72,6 +72,7 @@ class DistInfoStruct(ctypes.Structure):
         ("last_ms", ctypes.c_float * 4),
         ("last_sort_pass_ms", ctypes.c_float),
         ("last_sort_passes", ctypes.c_uint32),
+        ("last_sort_schedule", ctypes.c_uint32 * 2),
     ]
 
 

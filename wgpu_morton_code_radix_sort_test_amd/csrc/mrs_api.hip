@@ -763,10 +763,40 @@ static uint32_t hybrid_msd_bits(const mrs_plan* plan, uint32_t n)
     return bits;
 }
 
+// How the two scatters and the local sort share the key: passes A and B take `msd_bits` bits from
+// `shift` up (of the key itself, or, windowed, of (key >> shift) - base), the local sort bits
+// [begin_bit, shift).
+struct HybridSplit {
+    uint32_t msd_bits, shift, base;
+    bool windowed;
+};
+
+// The split for keys known to lie in [lo, hi]: with 14, 15 or 16 bits for passes A and B, the
+// smallest shift that leaves at most that many sub-buckets over the window; the first of the three
+// whose sub-buckets would hold about 5000 pairs or fewer if the keys were spread evenly (a window
+// that is a little wider than a power of two needs the next shift, and with it twice the
+// sub-bucket size) and whose local sort gets at most 16 bits.  False when there is none (a window
+// too wide for this n, or so narrow that its keys cannot spread) or the window is empty.
+static bool hybrid_window_split(const mrs_plan* plan, uint32_t n, uint64_t lo, uint64_t hi, HybridSplit* out)
+{
+    if (hi < lo || hi > 0xFFFFFFFFull) return false;
+    const uint32_t begin = plan->desc.begin_bit;
+    for (uint32_t bits = 14; bits <= 16; ++bits) {
+        uint32_t shift = begin + 2;  // the local sort takes two digits of at least one bit
+        while (shift < 32 && ((hi >> shift) - (lo >> shift)) >= (1ull << bits)) ++shift;
+        const uint64_t subs = (hi >> shift) - (lo >> shift) + 1;
+        if (shift - begin <= 16 && n / subs <= 5120) {
+            *out = HybridSplit{bits, shift, static_cast<uint32_t>(lo >> shift), true};
+            return true;
+        }
+    }
+    return false;
+}
+
 // The schedule of an MRS_ALGO_HYBRID plan (mrs_hybrid.hpp): both pass sequences are enqueued and the
 // device runs one of them.
 static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* vals_a, void* keys_b, void* vals_b,
-                             hipStream_t s, bool indexed)
+                             hipStream_t s, bool indexed, const HybridSplit& split)
 {
     const uint32_t num_tiles = (n32 + plan->tile_items - 1) / plan->tile_items;
     const uint32_t xcd_block = begin_ticketed_call(plan->ctx, s, plan->lineage);
@@ -776,10 +806,10 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     if (int rc = mark(plan, "memset", s)) return rc;
     const uint32_t begin_bit = plan->desc.begin_bit, end_bit = plan->desc.end_bit;
     const int hist_grid = hybrid_histogram_grid(plan->ctx->num_cus, n32);
-    const uint32_t msd_bits = hybrid_msd_bits(plan, n32);
+    const uint32_t msd_bits = split.msd_bits;
     const uint32_t bits_a = (msd_bits + 1) / 2, bits_b = msd_bits - bits_a;  // 7 or 8 each
-    if (int rc = hybrid_launch_histogram(static_cast<const uint32_t*>(keys_a), n32, end_bit - msd_bits, msd_bits, hist_grid,
-                                         plan->hyb_packed, plan->hyb_header, s))
+    if (int rc = hybrid_launch_histogram(static_cast<const uint32_t*>(keys_a), n32, split.shift, msd_bits, split.windowed,
+                                         split.base, hist_grid, plan->hyb_packed, plan->hyb_header, s))
         return rc;
     if (int rc = mark(plan, "msd_histogram", s)) return rc;
     // MRS_HYBRID_FORCE_FALLBACK: test aid, the device takes the plan's ordinary passes whatever the keys are
@@ -815,14 +845,16 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     a.vals_in = vals_a;
     a.keys_out = keys_b;
     a.vals_out = vals_b;
-    a.shift = end_bit - bits_a;
+    a.shift = split.windowed ? split.shift : split.shift + bits_b;
     a.mask = (1u << bits_a) - 1u;
+    a.window_base = split.base;
+    a.window_low = bits_b;
     a.digit_base = plan->hyb_tables->bucket_start;
     a.status = plan->status;
     a.tile_counter = plan->control->tile_counter[kMaxPasses - 2];
     a.index_payload = indexed;
-    if (int rc = hybrid_launch_pass(false, false, plan->threads, plan->kpt, a, plan->hyb_header, plan->hyb_tables, kHybRun,
-                                    num_tiles, s))
+    if (int rc = hybrid_launch_pass(false, false, split.windowed, plan->threads, plan->kpt, a, plan->hyb_header,
+                                    plan->hyb_tables, kHybRun, num_tiles, s))
         return rc;
     if (int rc = mark(plan, "msd_pass_a", s)) return rc;
     // pass B: b -> a by the next digit, bucket by bucket
@@ -830,19 +862,20 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     a.vals_in = vals_b;
     a.keys_out = keys_a;
     a.vals_out = vals_a;
-    a.shift = end_bit - msd_bits;
+    a.shift = split.shift;
     a.mask = (1u << bits_b) - 1u;
+    a.window_low = 0;
     a.digit_base = nullptr;
     a.status = plan->status + region;
     a.tile_counter = plan->control->tile_counter[kMaxPasses - 1];
     a.index_payload = 0;
     a.xcd_block = xcd_block * 2;  // chains end with their bucket: larger blocks cost less here (0.834 -> 0.822 ms at 2^28)
-    if (int rc = hybrid_launch_pass(true, false, plan->threads, plan->kpt, a, plan->hyb_header, plan->hyb_tables, kHybRun,
-                                    num_tiles + kHybBuckets, s))
+    if (int rc = hybrid_launch_pass(true, false, split.windowed, plan->threads, plan->kpt, a, plan->hyb_header,
+                                    plan->hyb_tables, kHybRun, num_tiles + kHybBuckets, s))
         return rc;
     if (int rc = mark(plan, "msd_pass_b", s)) return rc;
     // the remaining bits, inside LDS, in place
-    const uint32_t low_bits = end_bit - msd_bits - begin_bit;  // 9..16
+    const uint32_t low_bits = split.shift - begin_bit;  // 9..16, or 2..16 under a window
     const uint32_t bits1 = (low_bits + 1) / 2;
     if (int rc = hybrid_launch_local_sort(static_cast<uint32_t*>(keys_a), static_cast<uint32_t*>(vals_a), plan->hyb_header,
                                           plan->hyb_tables, begin_bit, bits1, low_bits - bits1, 1u << msd_bits,
@@ -864,7 +897,7 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
         a.status = plan->status + static_cast<size_t>(pass) * region;
         a.tile_counter = plan->control->tile_counter[pass];
         a.index_payload = indexed && pass == 0;
-        if (int rc = hybrid_launch_pass(false, true, plan->threads, plan->kpt, a, plan->hyb_header, plan->hyb_tables,
+        if (int rc = hybrid_launch_pass(false, true, false, plan->threads, plan->kpt, a, plan->hyb_header, plan->hyb_tables,
                                         kHybFallback, persistent_grid, s))
             return rc;
         if (int rc = mark(plan, "fallback_pass", s)) return rc;
@@ -878,8 +911,10 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
 // `primed`: the plan's control block already holds the digit histograms of exactly these keys.
 // `indexed`: the payload of input element i is i; vals_a is ping-pong space only and is never read
 // before it is written.
+// `window`: null, or two key values every key is known to lie between (inclusive).
 static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b,
-                           hipStream_t s, int* result_in_b, bool primed, const char* who, bool indexed = false)
+                           hipStream_t s, int* result_in_b, bool primed, const char* who, bool indexed = false,
+                           const uint64_t* window = nullptr)
 {
     if (indexed && plan->desc.payload_bytes != 4)
         return fail(MRS_ERR_INVALID_ARGUMENT, "%s: the plan must sort 4-byte payloads (source indices)", who);
@@ -914,9 +949,20 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
         if (int rc = launch_small_sort(plan->desc.key_words, plan->radix_bits, a, s)) return rc;
         return mark(plan, "small_sort", s);
     }
-    plan->hyb_last = plan->hybrid && !primed && n >= hybrid_min_n(plan);
-    if (plan->hyb_last)
-        return sort_pairs_hybrid(plan, n32, keys_a, vals_a, keys_b, vals_b, s, indexed);
+    if (plan->hybrid && !primed) {
+        HybridSplit split{};
+        if (window) {
+            // keys of one slice of the key space (the sharded sort's local sorts)
+            const char* e = std::getenv("MRS_HYBRID_MIN_N");  // test aid, as in hybrid_min_n
+            const uint64_t min_n = e ? std::strtoull(e, nullptr, 10) : 3ull << 24;  // slices are never exact powers of two
+            plan->hyb_last = n >= min_n && hybrid_window_split(plan, n32, window[0], window[1], &split);
+        } else {
+            plan->hyb_last = n >= hybrid_min_n(plan);
+            const uint32_t msd_bits = hybrid_msd_bits(plan, n32);
+            split = HybridSplit{msd_bits, plan->desc.end_bit - msd_bits, 0u, false};
+        }
+        if (plan->hyb_last) return sort_pairs_hybrid(plan, n32, keys_a, vals_a, keys_b, vals_b, s, indexed, split);
+    }
     // 64-bit keys: passes whose digit is the same for every key are left out on the device
     // (see global_histogram_scan_kernel; MRS_NO_PASS_SKIP=1: A/B aid)
     static const bool no_pass_skip = std::getenv("MRS_NO_PASS_SKIP") != nullptr;
@@ -1305,9 +1351,9 @@ int partition_pass(mrs_plan* plan, uint64_t n, const void* keys_in, const void* 
 }
 
 int sort_pairs_internal(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b, hipStream_t s,
-                        int* result_in_b)
+                        int* result_in_b, const uint64_t* window)
 {
-    return sort_pairs_impl(plan, n, keys_a, vals_a, keys_b, vals_b, s, result_in_b, false, "mrs_dist_sort_pairs");
+    return sort_pairs_impl(plan, n, keys_a, vals_a, keys_b, vals_b, s, result_in_b, false, "mrs_dist_sort_pairs", false, window);
 }
 
 int record_mark(mrs_plan* plan, const char* label, hipStream_t s) { return mark(plan, label, s); }

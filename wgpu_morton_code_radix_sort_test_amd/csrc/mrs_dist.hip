@@ -548,6 +548,10 @@ extern "C" int mrs_dist_create(mrs_context* ctx, mrs_comm* comm, const mrs_dist_
     pd.tile_items = 0;
     if (int rc = mrs_plan_create(ctx, &pd, &d->part_plan)) return bail(rc);
     pd.n = d->chunks == 1 ? d->recv_capacity : d->chunk_capacity;
+    // (u32 key, u32 payload) pieces of 2^26 pairs and more take the three-move schedule, split over
+    // the piece's own window of the key space (the cut keys on either side of it)
+    if (desc->key_words == 1 && desc->payload_bytes == 4 && desc->end_bit >= 25 && desc->end_bit <= 32 && pd.n < (1ull << 30))
+        pd.algo = MRS_ALGO_HYBRID;
     for (int c = 0; c < d->chunks; ++c)
         if (int rc = mrs_plan_create(ctx, &pd, &d->sort_plan[c])) return bail(rc);
     d->part_plan->lineage = d;
@@ -626,6 +630,15 @@ extern "C" int mrs_dist_get_info(mrs_dist* dist, mrs_dist_info* info)
     info->last_levels = dist->last_levels;
     info->last_exact_cuts = dist->last_exact_cuts;
     info->last_n_out = dist->last_n_out;
+    {
+        // what the device chose is in device memory: wait for everything this rank enqueued
+        MRS_HIP_TRY(hipDeviceSynchronize());
+        for (int c = 0; c < dist->chunks && c < 2; ++c) {
+            int32_t schedule = 0;
+            if (int rc = mrs_plan_get_schedule(dist->sort_plan[c], nullptr, &schedule, nullptr)) return rc;
+            info->last_sort_schedule[c] = static_cast<uint32_t>(schedule);
+        }
+    }
     if (dist->timing && dist->marks_valid) {
         MRS_HIP_TRY(hipEventSynchronize(dist->marks[4]));
         for (int i = 0; i < 4; ++i) MRS_HIP_TRY(hipEventElapsedTime(&info->last_ms[i], dist->marks[i], dist->marks[i + 1]));
@@ -636,7 +649,8 @@ extern "C" int mrs_dist_get_info(mrs_dist* dist, mrs_dist_info* info)
         float sum = 0.f;
         uint32_t passes = 0;
         for (int i = 0; i < count; ++i)
-            if (std::strcmp(labels + 32 * i, "onesweep_pass") == 0) {
+            if (std::strcmp(labels + 32 * i, "onesweep_pass") == 0 || std::strcmp(labels + 32 * i, "msd_pass_a") == 0 ||
+                std::strcmp(labels + 32 * i, "msd_pass_b") == 0) {
                 sum += ms[i];
                 ++passes;
             }
@@ -824,8 +838,13 @@ extern "C" int mrs_dist_sort_pairs(mrs_dist* dist, uint64_t n_local, const void*
         }
         if (c == K - 1 && d->timing) MRS_HIP_TRY(hipEventRecord(d->marks[3], s));
         auto at = [&](void* base, size_t elem) { return base ? static_cast<char*>(base) + region * elem : nullptr; };
+        // every key of piece c lies between the cuts on either side of destination slice me * K + c
+        const int v = me * K + c;
+        const uint64_t top_key = d->desc.end_bit >= 64 ? ~0ull : (1ull << d->desc.end_bit) - 1ull;
+        const uint64_t window[2] = {v == 0 ? 0ull : sp.key(v - 1), v == P * K - 1 ? top_key : sp.key(v)};
         if (int rc = sort_pairs_internal(d->sort_plan[c], piece, at(d->recv_k, d->key_bytes), at(d->recv_v, d->val_bytes),
-                                         at(d->tmp_k, d->key_bytes), at(d->tmp_v, d->val_bytes), sort_stream, &in_b))
+                                         at(d->tmp_k, d->key_bytes), at(d->tmp_v, d->val_bytes), sort_stream, &in_b,
+                                         P * K > 1 ? window : nullptr))
             return rc;
         region = ro;
     }

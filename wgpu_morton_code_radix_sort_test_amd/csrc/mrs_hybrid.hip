@@ -19,7 +19,7 @@ namespace mrs {
 __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                  uint32_t vectors, uint32_t shift, uint32_t bits,
                                                                  uint32_t* __restrict__ packed, HybridHeader* hdr,
-                                                                 uint32_t cap)
+                                                                 uint32_t cap, uint32_t window_base, uint32_t windowed)
 {
     constexpr int THREADS = 1024, UNROLL = 4;
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kHybPackedWords];
@@ -37,8 +37,17 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
     __syncthreads();
     uint32_t mine = 0;
     uint32_t most = 0;  // largest count this lane has seen in a field before its own increment
-    auto count = [&](uint32_t k) {
-        const uint32_t b = __builtin_amdgcn_ubfe(k, shift, bits);  // bits <= 16: counters beyond 2^bits stay zero
+    auto count = [&](uint32_t k) __attribute__((always_inline)) {
+        uint32_t b = __builtin_amdgcn_ubfe(k, shift, bits);  // bits <= 16: counters beyond 2^bits stay zero
+        if (windowed) {  // uniform
+            // sub-bucket = (key >> shift) - window_base; a key outside the window ends the count
+            // (the other schedule sorts any keys)
+            b = (k >> shift) - window_base;
+            if (b >> bits) {
+                most = cap;
+                b = 0;
+            }
+        }
         const uint32_t half = (b & 1u) * 16u;
         const uint32_t old = atomicAdd(&s_cnt[b >> 1], 1u << half);
         const uint32_t seen = (old >> half) & 0xFFFFu;
@@ -75,6 +84,7 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
         count(keys[i]);
         mine += 1;
     }
+    if (most >= cap) s_stop = 1;  // seen in the last steps, which do not look
     __syncthreads();
     if (s_stop != 0) {  // uniform: the counts are incomplete and nobody will read them
         if (tid == 0) atomicOr(&hdr->overflow, 1u);
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
 // covers TILE elements from bucket_start[b] + (t - first_tile[b]) * TILE (fewer in the bucket's
 // last tile), and its chained scan starts at first_tile[b] with the sub-bucket starts of b as
 // digit bases.  PERSISTENT: the workgroup draws tiles until none is left.
-template <bool SEG, bool PERSISTENT, int THREADS, int KPT>
+template <bool SEG, bool PERSISTENT, int MAP, int THREADS, int KPT>
 __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs a, const HybridHeader* __restrict__ hdr,
                                                                   const HybridTables* __restrict__ tb,
                                                                   const uint32_t run_if_mode)
@@ -295,16 +305,16 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
             PassArgs b = a;
             b.digit_base = tb->sub_start + seg * (a.mask + 1u);  // the bucket's sub-buckets, a.mask + 1 of them
             if (remaining >= static_cast<uint32_t>(S::TILE))
-                process_tile<kModeOnesweep, kRankAtomic, kMapNone, true, uint32_t>(b, sh, tile, S::TILE, base, first);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, true, uint32_t>(b, sh, tile, S::TILE, base, first);
             else
-                process_tile<kModeOnesweep, kRankAtomic, kMapNone, false, uint32_t>(b, sh, tile, remaining, base, first);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, false, uint32_t>(b, sh, tile, remaining, base, first);
         } else {
             const uint32_t remaining = a.n - tile * static_cast<uint32_t>(S::TILE);
             const unsigned long long base = static_cast<unsigned long long>(tile) * S::TILE;
             if (remaining >= static_cast<uint32_t>(S::TILE))
-                process_tile<kModeOnesweep, kRankAtomic, kMapNone, true, uint32_t>(a, sh, tile, S::TILE, base, 0u);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, true, uint32_t>(a, sh, tile, S::TILE, base, 0u);
             else
-                process_tile<kModeOnesweep, kRankAtomic, kMapNone, false, uint32_t>(a, sh, tile, remaining, base, 0u);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, false, uint32_t>(a, sh, tile, remaining, base, 0u);
         }
         if (!PERSISTENT) return;
         __syncthreads();  // the tile's LDS image is dead
@@ -483,12 +493,12 @@ int hybrid_local_sort_grid(int num_cus)
     return g < static_cast<int>(kLocalMinGrid) ? static_cast<int>(kLocalMinGrid) : g;
 }  // 80 KiB of LDS each: two per compute unit
 
-int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t bits, int grid, uint32_t* packed,
-                            HybridHeader* hdr, hipStream_t s)
+int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t bits, bool windowed, uint32_t window_base,
+                            int grid, uint32_t* packed, HybridHeader* hdr, hipStream_t s)
 {
     const uint32_t vectors = (reinterpret_cast<uintptr_t>(keys) & 15u) ? 0u : n / 4u;
     hipLaunchKernelGGL(hybrid_histogram_kernel, dim3(grid), dim3(1024), 0, s, keys, n, vectors, shift, bits, packed, hdr,
-                       kHybLocalCap);
+                       kHybLocalCap, window_base, windowed ? 1u : 0u);
     MRS_CHECK_LAUNCH("hybrid_histogram_kernel");
     return MRS_OK;
 }
@@ -504,30 +514,34 @@ int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, H
     return MRS_OK;
 }
 
-template <bool SEG, bool PERSISTENT>
+template <bool SEG, bool PERSISTENT, int MAP>
 static int launch_pass_shape(int threads, int kpt, const PassArgs& a, const HybridHeader* hdr, const HybridTables* tables,
                              uint32_t run_if_mode, uint32_t grid, hipStream_t s)
 {
     if (threads == 1024 && kpt == 32)
-        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, PERSISTENT, 1024, 32>), dim3(grid), dim3(1024), 0, s, a, hdr, tables, run_if_mode);
+        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, PERSISTENT, MAP, 1024, 32>), dim3(grid), dim3(1024), 0, s, a, hdr, tables, run_if_mode);
     else if (threads == 512 && kpt == 8)
-        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, PERSISTENT, 512, 8>), dim3(grid), dim3(512), 0, s, a, hdr, tables, run_if_mode);
+        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, PERSISTENT, MAP, 512, 8>), dim3(grid), dim3(512), 0, s, a, hdr, tables, run_if_mode);
     else
         return fail(MRS_ERR_UNSUPPORTED, "no gated pass kernel for %d threads x %d keys per thread", threads, kpt);
     MRS_CHECK_LAUNCH("hybrid_pass_kernel");
     return MRS_OK;
 }
 
-int hybrid_launch_pass(bool segmented, bool persistent, int threads, int kpt, const PassArgs& a, const HybridHeader* hdr,
-                       const HybridTables* tables, uint32_t run_if_mode, uint32_t grid, hipStream_t s)
+int hybrid_launch_pass(bool segmented, bool persistent, bool windowed, int threads, int kpt, const PassArgs& a,
+                       const HybridHeader* hdr, const HybridTables* tables, uint32_t run_if_mode, uint32_t grid, hipStream_t s)
 {
     if (a.wide_status) return fail(MRS_ERR_UNSUPPORTED, "gated passes use 32-bit tile status words");
     if (grid == 0) grid = 1;
-    if (segmented)
-        return persistent ? launch_pass_shape<true, true>(threads, kpt, a, hdr, tables, run_if_mode, grid, s)
-                          : launch_pass_shape<true, false>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
-    return persistent ? launch_pass_shape<false, true>(threads, kpt, a, hdr, tables, run_if_mode, grid, s)
-                      : launch_pass_shape<false, false>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
+    if (persistent) {  // the plan's ordinary passes: whole array, plain bit-field digits
+        if (segmented || windowed) return fail(MRS_ERR_UNSUPPORTED, "persistent gated passes are plain digit passes");
+        return launch_pass_shape<false, true, kMapNone>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
+    }
+    if (windowed)
+        return segmented ? launch_pass_shape<true, false, kMapWindow>(threads, kpt, a, hdr, tables, run_if_mode, grid, s)
+                         : launch_pass_shape<false, false, kMapWindow>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
+    return segmented ? launch_pass_shape<true, false, kMapNone>(threads, kpt, a, hdr, tables, run_if_mode, grid, s)
+                     : launch_pass_shape<false, false, kMapNone>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
 }
 
 int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,

@@ -57,8 +57,10 @@ int hybrid_histogram_grid(int num_cus, uint64_t n);
 int hybrid_local_sort_grid(int num_cus);
 
 // Histogram of the `bits` <= 16 key bits from `shift` up: one packed table per workgroup.
-int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t bits, int grid, uint32_t* packed,
-                            HybridHeader* hdr, hipStream_t s);
+// windowed: of (key >> shift) - window_base instead, which must be below 2^bits for every key (a
+// key outside that window makes the device refuse the schedule).
+int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t bits, bool windowed, uint32_t window_base,
+                            int grid, uint32_t* packed, HybridHeader* hdr, hipStream_t s);
 // Sum of the `grid` packed tables, its exclusive scan, the tile table of pass B and the decision.
 int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridHeader* hdr, uint32_t n,
                        uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, hipStream_t s);
@@ -66,7 +68,8 @@ int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, H
 // chains per bucket, a.digit_base and a.num_tiles ignored); otherwise a pass over the whole array.
 // persistent: `grid` workgroups draw tiles until none is left (an idle launch then costs `grid`
 // workgroups, not one per tile).
-int hybrid_launch_pass(bool segmented, bool persistent, int threads, int kpt, const PassArgs& a,
+// windowed: the digits are fields of (key >> a.shift) - a.window_base (PassArgs).
+int hybrid_launch_pass(bool segmented, bool persistent, bool windowed, int threads, int kpt, const PassArgs& a,
                        const HybridHeader* hdr, const HybridTables* tables, uint32_t run_if_mode, uint32_t grid,
                        hipStream_t s);
 // Sorts every sub-bucket in place on bits [shift, shift + bits1 + bits2).

@@ -60,6 +60,11 @@ struct PassArgs {
     const void* splitters;
     uint32_t num_splitters;
     uint32_t exact_mask;
+    // kMapWindow passes: digit = (((key >> shift) - window_base) >> window_low) & mask, for keys known
+    // to lie in a window of the key space (the most-significant-digit-first schedule on one slice
+    // of a sharded sort)
+    uint32_t window_base;
+    uint32_t window_low;
     // three-kernel: scanned block histogram, digit-major [radix][num_tiles]
     const uint32_t* scanned;
     // onesweep
@@ -187,8 +192,10 @@ int partition_internal(mrs_plan* plan, uint64_t n, const void* keys_in, const vo
 int partition_pass(mrs_plan* plan, uint64_t n, const void* keys_in, const void* vals_in, void* keys_out, void* vals_out,
                    uint32_t shift, uint32_t bits, const uint8_t* map_dev, const void* splitters_dev, uint32_t num_splitters,
                    uint32_t exact_mask, bool scan_histogram, hipStream_t s);
+// `window` (may be null): two key values every key lies between, inclusive; lets an MRS_ALGO_HYBRID
+// plan split the window, not the whole key space, into sub-buckets.
 int sort_pairs_internal(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b, hipStream_t s,
-                        int* result_in_b);
+                        int* result_in_b, const uint64_t* window = nullptr);
 
 // scan (mrs_scan.hip)
 uint64_t scan_partials_len(uint64_t len);

@@ -116,13 +116,15 @@ __device__ __forceinline__ uint32_t splitter_class(KeyT k, const KeyT* split, ui
 // a splitter, whose keys are compared one by one.  The last form puts a data-dependent branch
 // behind every table lookup (the lookups of a thread's keys no longer overlap), so the host
 // selects it only for tables that do contain the mark: skewed inputs of the sharded sort.
-enum MapMode { kMapNone = 0, kMapTable = 1, kMapTableAndSplitters = 2 };
+// kMapWindow: the digit is a bit field of (key >> shift) - window_base, see PassArgs.
+enum MapMode { kMapNone = 0, kMapTable = 1, kMapTableAndSplitters = 2, kMapWindow = 3 };
 
 template <int MAP, typename KeyT>
 __device__ __forceinline__ uint32_t key_digit(KeyT k, const PassArgs& a)
 {
+    if constexpr (MAP == kMapWindow) return ((static_cast<uint32_t>(k >> a.shift) - a.window_base) >> a.window_low) & a.mask;
     uint32_t d = static_cast<uint32_t>(k >> a.shift) & a.mask;
-    if constexpr (MAP != kMapNone) d = a.digit_map[d];
+    if constexpr (MAP == kMapTable || MAP == kMapTableAndSplitters) d = a.digit_map[d];
     if constexpr (MAP == kMapTableAndSplitters) {
         if (d == kMapBySplitters) d = splitter_class<KeyT>(k, static_cast<const KeyT*>(a.splitters), a.num_splitters, a.exact_mask);
     }
