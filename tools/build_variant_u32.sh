@@ -7,4 +7,4 @@ for f in mrs_radix_u32 mrs_radix_u32_atomic; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -I../../include -I. "$@" -c $f.hip -o $obj/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/libmrs_$name.so $obj/*.o mrs_api.o mrs_split.o mrs_dist.o mrs_radix_u64.o mrs_radix_u64_atomic.o mrs_scan.o mrs_morton.o mrs_probe.o mrs_small_sort.o mrs_gather.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch/libmrs_$name.so $obj/*.o mrs_api.o mrs_hybrid.o mrs_split.o mrs_dist.o mrs_radix_u64.o mrs_radix_u64_atomic.o mrs_scan.o mrs_morton.o mrs_probe.o mrs_small_sort.o mrs_gather.o -ldl

@@ -746,14 +746,15 @@ static uint64_t hybrid_min_n(const mrs_plan* plan)
     return width <= 30 ? 1ull << 26 : (width == 31 ? 3ull << 25 : 1ull << 27);
 }
 
-// Key bits passes A and B take together: enough for sub-buckets of at most about 4096 pairs on
-// evenly spread keys, at least 14, and at least so many that 16 bits or fewer are left for the
-// local sort.  A takes the larger half.
+// Key bits passes A and B take together: enough for sub-buckets of at most about 5000 pairs on
+// evenly spread keys (two thirds of what a workgroup holds; fewer, fuller sub-buckets cost the
+// local sort fewer visits), at least 14, and at least so many that 16 bits or fewer are left for
+// the local sort.  A takes the larger half.
 static uint32_t hybrid_msd_bits(const mrs_plan* plan, uint32_t n)
 {
     const uint32_t width = plan->desc.end_bit - plan->desc.begin_bit;
     uint32_t bits = 14;
-    while (bits < 16 && (static_cast<uint64_t>(n) >> bits) > 4096) ++bits;
+    while (bits < 16 && (static_cast<uint64_t>(n) >> bits) > 5120) ++bits;
     // MRS_HYBRID_MSD_BITS: test aid, the finer splits on inputs a checker can follow
     if (const char* e = std::getenv("MRS_HYBRID_MSD_BITS")) {
         const uint32_t forced = static_cast<uint32_t>(std::atoi(e));
