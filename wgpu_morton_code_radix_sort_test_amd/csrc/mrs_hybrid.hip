@@ -251,7 +251,11 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
 // the buckets pass A made: tile t belongs to the bucket b with first_tile[b] <= t < first_tile[b+1],
 // covers TILE elements from bucket_start[b] + (t - first_tile[b]) * TILE (fewer in the bucket's
 // last tile), and its chained scan starts at first_tile[b] with the sub-bucket starts of b as
-// digit bases.  PERSISTENT: the workgroup draws tiles until none is left.
+// digit bases.  PERSISTENT: the workgroup draws tiles until none is left (same time per pass as a
+// workgroup per tile, 0.86-0.88 ms at 2^28, also when the next ticket is drawn during the write-out:
+// the hand-over from tile to tile is not what bounds a pass; but a switched-off launch costs 0.005 ms
+// instead of 0.1, and one that runs holds every compute unit until the pass ends, which a collective
+// waiting on another stream feels).
 template <bool SEG, bool PERSISTENT, int MAP, int THREADS, int KPT>
 __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs a, const HybridHeader* __restrict__ hdr,
                                                                   const HybridTables* __restrict__ tb,
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
     using S = PassShared<8, THREADS, KPT, uint32_t, uint32_t>;
     __shared__ S sh;
     __shared__ uint32_t s_seg[4];
-    const uint32_t tid = threadIdx.x;
+    uint32_t tid = threadIdx.x;
     const uint32_t mode = hdr->mode;  // uniform
     if (PERSISTENT && mode != run_if_mode) return;
     const uint32_t num_tiles = SEG ? hdr->num_tiles_b : a.num_tiles;
@@ -274,6 +278,11 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
         }
     }
     for (;;) {
+        if constexpr (PERSISTENT) {
+            // nothing derived from the thread's number is to be carried over from tile to tile (the
+            // registers are needed inside the tile: 19 spilled values and 9 % of the time otherwise)
+            asm volatile("" : "+v"(tid));
+        }
         // The gate word and the first ticket travel together: a workgroup of a launch that runs
         // does not wait for one after the other, and one of a launch that is switched off leaves
         // as soon as the word is there (having wasted a ticket of a counter nobody else reads).
@@ -305,18 +314,21 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
             PassArgs b = a;
             b.digit_base = tb->sub_start + seg * (a.mask + 1u);  // the bucket's sub-buckets, a.mask + 1 of them
             if (remaining >= static_cast<uint32_t>(S::TILE))
-                process_tile<kModeOnesweep, kRankAtomic, MAP, true, uint32_t>(b, sh, tile, S::TILE, base, first);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, true, uint32_t>(b, sh, tile, S::TILE, base, first, tid);
             else
-                process_tile<kModeOnesweep, kRankAtomic, MAP, false, uint32_t>(b, sh, tile, remaining, base, first);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, false, uint32_t>(b, sh, tile, remaining, base, first, tid);
         } else {
             const uint32_t remaining = a.n - tile * static_cast<uint32_t>(S::TILE);
             const unsigned long long base = static_cast<unsigned long long>(tile) * S::TILE;
             if (remaining >= static_cast<uint32_t>(S::TILE))
-                process_tile<kModeOnesweep, kRankAtomic, MAP, true, uint32_t>(a, sh, tile, S::TILE, base, 0u);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, true, uint32_t>(a, sh, tile, S::TILE, base, 0u, tid);
             else
-                process_tile<kModeOnesweep, kRankAtomic, MAP, false, uint32_t>(a, sh, tile, remaining, base, 0u);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, false, uint32_t>(a, sh, tile, remaining, base, 0u, tid);
         }
         if (!PERSISTENT) return;
+        // A look-back that gave up has raised the plan's error flag: the output is lost, the ticket of
+        // the next tile may never have been drawn, and every other workgroup gives up on that flag.
+        if (sh.abort) return;  // uniform: read after the barrier behind which it was written
         __syncthreads();  // the tile's LDS image is dead
     }
 }

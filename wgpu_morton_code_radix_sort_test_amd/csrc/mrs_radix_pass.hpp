@@ -355,12 +355,15 @@ struct PassShared {
 // `tile_base`: index of the tile's first element in the arrays; `chain_first`: the first tile of
 // the chained scan this tile belongs to (0 when the whole input is one chain; the first tile of
 // the tile's segment when every segment of the input is scanned on its own, in which case
-// a.digit_base is the segment's).
+// a.digit_base is the segment's).  `tid`: threadIdx.x (a workgroup that loops over tiles passes a
+// copy whose origin the compiler cannot see, so that nothing derived from it is kept in registers
+// from one tile to the next).
 template <int MODE, int RANK, int MAP, bool FULL, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT,
           typename ValT>
 __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS, THREADS, KPT, KeyT, ValT>& sh,
                                              const uint32_t tile, const uint32_t tile_valid,
-                                             const unsigned long long tile_base, const uint32_t chain_first)
+                                             const unsigned long long tile_base, const uint32_t chain_first,
+                                             const int tid)
 {
     using S = PassShared<BITS, THREADS, KPT, KeyT, ValT>;
     using SB = StatusBits<StatusT>;
@@ -374,7 +377,6 @@ __device__ __forceinline__ void process_tile(const PassArgs& a, PassShared<BITS,
     // 4 GiB, so byte offsets into them fit 32 bits there.
     constexpr bool OFF32 = MODE == kModeOnesweep && sizeof(StatusT) == 4;
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const uint32_t my_first = wave * 64 * KPT + lane;  // element of item 0 inside the tile
@@ -839,9 +841,9 @@ __device__ __forceinline__ void run_digit_pass(const PassArgs& a, PassShared<BIT
     // vector compare followed by s_cselect_b32 on a stale SCC (tools/check_scc.py finds these).
     const uint32_t remaining = a.n - tile * static_cast<uint32_t>(S::TILE);
     if (remaining >= static_cast<uint32_t>(S::TILE))
-        process_tile<MODE, RANK, MAP, true, StatusT>(a, sh, tile, S::TILE, static_cast<unsigned long long>(tile) * S::TILE, 0u);
+        process_tile<MODE, RANK, MAP, true, StatusT>(a, sh, tile, S::TILE, static_cast<unsigned long long>(tile) * S::TILE, 0u, tid);
     else
-        process_tile<MODE, RANK, MAP, false, StatusT>(a, sh, tile, remaining, static_cast<unsigned long long>(tile) * S::TILE, 0u);
+        process_tile<MODE, RANK, MAP, false, StatusT>(a, sh, tile, remaining, static_cast<unsigned long long>(tile) * S::TILE, 0u, tid);
 }
 
 template <int MODE, int RANK, int MAP, typename StatusT, int BITS, int THREADS, int KPT, typename KeyT, typename ValT>
