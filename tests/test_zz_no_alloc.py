@@ -35,7 +35,9 @@ def _noalloc_sort(ctx, keys, vals, n, begin, end):
     torch.cuda.synchronize()
     free_before = torch.cuda.mem_get_info()[0]
     in_b = ctx.sort_pairs_noalloc(ka, va, kb, vb, n, begin, end)
-    assert torch.cuda.mem_get_info()[0] == free_before  # the device's free memory did not move
+    # the call took no device memory (the runtime may hand back memory of objects destroyed earlier,
+    # e.g. a stream of a test before this one, at any moment: free memory may grow, never shrink)
+    assert torch.cuda.mem_get_info()[0] >= free_before
     assert ctx.attribute(ctx.ATTR_NOALLOC_TIMEOUT) == 0
     return (kb, vb, in_b) if in_b else (ka, va, in_b)
 

@@ -242,6 +242,21 @@ static void end_ticketed_call(const mrs_context* ctx, hipStream_t s, uint32_t bl
     }
 }
 
+// A stream that is about to be destroyed must not stay behind as "where the last die-aware call
+// ran": the next call would query an event whose stream is gone.  Waits for the stream first.
+void forget_stream_activity(int device, hipStream_t s)
+{
+    if (device < 0 || device >= kMaxDevices || !s) return;
+    (void)hipStreamSynchronize(s);
+    DeviceActivity& a = g_activity[device];
+    std::lock_guard<std::mutex> lock(a.m);
+    if (a.stream == s) {
+        a.stream = nullptr;
+        a.lineage = nullptr;
+        a.recorded = false;
+    }
+}
+
 static int launch_pass(const mrs_plan* p, int mode, const PassArgs& args, hipStream_t s)
 {
     PassArgs a = args;
@@ -958,7 +973,9 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
             const uint64_t min_n = e ? std::strtoull(e, nullptr, 10) : 3ull << 24;  // slices are never exact powers of two
             plan->hyb_last = n >= min_n && hybrid_window_split(plan, n32, window[0], window[1], &split);
         } else {
-            plan->hyb_last = n >= hybrid_min_n(plan);
+            // above about 2^28.7 pairs even evenly spread keys leave sub-buckets a workgroup cannot hold
+            // (6500 on average, 7680 at most): the device would refuse, so it is not asked
+            plan->hyb_last = n >= hybrid_min_n(plan) && (n >> 16) <= 6500;
             const uint32_t msd_bits = hybrid_msd_bits(plan, n32);
             split = HybridSplit{msd_bits, plan->desc.end_bit - msd_bits, 0u, false};
         }

@@ -472,9 +472,15 @@ extern "C" int mrs_comm_destroy(mrs_comm* comm)
     return MRS_OK;
 }
 
+// Handles of several in-process ranks are destroyed by their threads at the same time; the runtime
+// calls below are made by one thread at a time (a process was seen to abort inside them otherwise).
+static std::mutex g_destroy_mutex;
+
 static void free_dist(mrs_dist* d)
 {
     if (!d) return;
+    std::lock_guard<std::mutex> lock(g_destroy_mutex);
+    if (d->side && d->ctx) forget_stream_activity(d->ctx->device, d->side);
     if (d->part_plan) (void)mrs_plan_destroy(d->part_plan);
     for (mrs_plan* p : d->sort_plan)
         if (p) (void)mrs_plan_destroy(p);

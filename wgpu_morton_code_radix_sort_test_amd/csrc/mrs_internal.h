@@ -194,6 +194,7 @@ int partition_pass(mrs_plan* plan, uint64_t n, const void* keys_in, const void* 
                    uint32_t exact_mask, bool scan_histogram, hipStream_t s);
 // `window` (may be null): two key values every key lies between, inclusive; lets an MRS_ALGO_HYBRID
 // plan split the window, not the whole key space, into sub-buckets.
+void forget_stream_activity(int device, hipStream_t s);
 int sort_pairs_internal(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b, void* vals_b, hipStream_t s,
                         int* result_in_b, const uint64_t* window = nullptr);
 
