@@ -251,7 +251,9 @@ int mrs_morton_encode30_for_sort(mrs_plan* plan, const float* xyz_dev, uint64_t 
 /* mrs_sort_pairs that consumes the histograms mrs_morton_encode30_for_sort left in the plan.
  * Fails with MRS_ERR_INVALID_ARGUMENT unless it is the first call on the plan after that encoder
  * call and keys_a and n are the encoder's keys_dev and n; the caller vouches that the keys have
- * not been written since.  mrs_sort_pairs itself never uses left-over histograms. */
+ * not been written since.  mrs_sort_pairs itself never uses left-over histograms.  On an
+ * MRS_ALGO_HYBRID plan the left-over histograms only serve inputs that the plan sorts with its
+ * ordinary passes by size; otherwise the call is mrs_sort_pairs. */
 int mrs_sort_pairs_primed(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a, void* keys_b,
                           void* vals_b, void* stream, int* result_in_b);
 

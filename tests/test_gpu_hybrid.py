@@ -253,3 +253,57 @@ def test_fuzz(ctx, oracle, mrs, small_inputs_take_the_schedule):
         assert not in_b, what
         assert np.array_equal(ko, rk), what
         assert np.array_equal(vo, rv), what
+
+
+def test_two_streams_at_once(oracle, mrs, small_inputs_take_the_schedule):
+    """Two hybrid plans of two contexts sorting on two streams at the same time, every attribute at
+    its default: the second call finds the first one's die-aware passes in flight and deals its
+    tiles from a single list (pass B included), so neither can starve the other."""
+    n = 1 << 21
+    ctxs = [mrs.Context(0), mrs.Context(0)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    plans, bufs, host = [], [], []
+    for j in range(2):
+        keys = make_keys(oracle, n, 1, "morton30" if j == 0 else "random", seed=40 + j)
+        vals = make_vals(oracle, n, 1)
+        host.append((keys, vals))
+        plans.append(mrs.SortPlan(ctxs[j], n, key_words=1, payload_bytes=4, digit_bits=8, end_bit=30 if j == 0 else 32,
+                                  algo=mrs.ALGO_HYBRID))
+        ka, va = to_dev(keys, ctxs[j].device), to_dev(vals, ctxs[j].device)
+        bufs.append((ka, va, torch.empty_like(ka), torch.empty_like(va)))
+    torch.cuda.synchronize()
+    for rounds in range(3):
+        for j in range(2):
+            ka, va, kb, vb = bufs[j]
+            ka.copy_(to_dev(host[j][0], ctxs[j].device))
+            va.copy_(to_dev(host[j][1], ctxs[j].device))
+        torch.cuda.synchronize()
+        for j in range(2):
+            ka, va, kb, vb = bufs[j]
+            assert not plans[j].sort_pairs(ka, va, kb, vb, stream=streams[j])
+        for j in range(2):
+            streams[j].synchronize()
+            plans[j].check(stream=streams[j])
+            assert plans[j].schedule(stream=streams[j])[0] == plans[j].SCHEDULE_MSD
+            end = 30 if j == 0 else 32
+            rk, rv = oracle.stable_sort_pairs(host[j][0], host[j][1], n, 1, 1, 0, end)
+            assert np.array_equal(to_u32(bufs[j][0]), rk) and np.array_equal(to_u32(bufs[j][1]), rv), (rounds, j)
+    for p in plans:
+        p.close()
+
+
+def test_primed_call_on_a_hybrid_plan(ctx, oracle, mrs, small_inputs_take_the_schedule):
+    """mrs_morton_encode30_for_sort + mrs_sort_pairs_primed on a hybrid plan: the histograms the
+    encoder left serve the four passes only, the three-move schedule takes its own and runs."""
+    n = 300001
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, end_bit=30, algo=mrs.ALGO_HYBRID)
+    xyz = ctx.generate_points(9, n)
+    keys, idx = plan.morton_encode30_for_sort(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+    hk, hv = to_u32(keys).copy(), to_u32(idx).copy()
+    kb, vb = torch.empty_like(keys), torch.empty_like(idx)
+    assert not plan.sort_pairs_primed(keys, idx, kb, vb)
+    plan.check()
+    assert plan.schedule()[0] == plan.SCHEDULE_MSD
+    rk, rv = oracle.stable_sort_pairs(hk, hv, n, 1, 1, 0, 30)
+    assert np.array_equal(to_u32(keys), rk) and np.array_equal(to_u32(idx), rv)
+    plan.close()

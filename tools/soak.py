@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--log2n", type=int, default=28)
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--tile-items", type=int, default=0)
+    ap.add_argument("--hybrid", action="store_true",
+                    help="an MRS_ALGO_HYBRID plan over key bits [0, 30): two of three inputs are spread keys (the "
+                         "three-move schedule), the third makes the device refuse it; sizes vary from sort to sort")
     ap.add_argument("--u64", action="store_true",
                     help="64-bit keys + index; the high word is masked differently every iteration, so passes "
                          "with a constant digit (left out on the device) come and go")
@@ -64,13 +67,23 @@ def main():
     n = 1 << args.log2n
     if args.u64:
         return soak_u64(ctx, n, args)
-    plan = mrs.SortPlan(ctx, n, tile_items=args.tile_items)
+    if args.hybrid:
+        plan = mrs.SortPlan(ctx, n, end_bit=30, algo=mrs.ALGO_HYBRID)
+    else:
+        plan = mrs.SortPlan(ctx, n, tile_items=args.tile_items)
+    cap = n
     kb = torch.empty(n, dtype=torch.int32, device=ctx.device)
     vb = torch.empty(n, dtype=torch.int32, device=ctx.device)
     bad = 0
+    schedules = {}
     for it in range(args.iters):
+        if args.hybrid:
+            # sizes that move the split between the two scatters (14, 15, 16 bits) and the tile counts
+            n = cap - (it * 7919 * 1021) % (cap // 2) if it % 4 else cap
         if it % 3 == 2:
             keys = ctx.generate_u32(1000 + it, 1, n)
+            if args.hybrid:
+                keys &= 0x3FFFFFFF
             if it % 2 == 0:
                 keys &= 0xFF00FF  # few distinct digits in two passes, constant digits in the others
             idx = torch.arange(n, dtype=torch.int32, device=ctx.device)
@@ -79,9 +92,12 @@ def main():
             keys, idx = ctx.morton_encode30(xyz, [0, 0, 0], [1, 1, 1])
             del xyz
         ref = keys.clone()
-        in_b = plan.sort_pairs(keys, idx, kb, vb)
+        in_b = plan.sort_pairs(keys, idx, kb, vb, n=n)
         plan.check()
-        ok, ov = (kb, vb) if in_b else (keys, idx)
+        if args.hybrid:
+            which = plan.schedule()[0]
+            schedules[which] = schedules.get(which, 0) + 1
+        ok, ov = (kb[:n], vb[:n]) if in_b else (keys, idx)
         k64 = ok.to(torch.int64) & 0xFFFFFFFF
         sorted_ok = bool((k64[1:] >= k64[:-1]).all())
         gathered = ref[ov.to(torch.int64)]
@@ -94,7 +110,9 @@ def main():
             print(f"iteration {it}: sorted={sorted_ok} permutation={perm_ok} stable={stable_ok}", flush=True)
         if it % 10 == 9:
             print(f"{it + 1} sorts checked, {bad} bad", flush=True)
-    print("SOAK", "FAILED" if bad else "ok", f"({args.iters} sorts of 2^{args.log2n} pairs)")
+    if args.hybrid:
+        print("schedules (0 passes, 1 three moves, 2 refused by the device):", schedules)
+    print("SOAK", "FAILED" if bad else "ok", f"({args.iters} sorts of up to 2^{args.log2n} pairs)")
     sys.exit(1 if bad else 0)
 
 
