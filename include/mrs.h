@@ -159,6 +159,24 @@ int mrs_plan_get_passes_left_out(mrs_plan* plan, void* stream, uint32_t* left_ou
  * sub-buckets the device counted, 0 when it counted none, 0xFFFFFFFF when it stopped counting
  * because one workgroup's share of a sub-bucket alone was too large.  For tests and harnesses; the
  * reference always runs its one schedule (src/main.rs:594-665). */
+/* Host only, no GPU needed: how an MRS_ALGO_HYBRID plan for key bits [begin_bit, end_bit) would
+ * go about a sort of n pairs.  `window`: NULL, or two key values every key lies between (what the
+ * sharded sort knows of a rank's piece).  offered = 0: the plan's ordinary passes run on the
+ * host's decision (n too small or too large for sub-buckets of a workgroup's size, or no split of
+ * the window leaves the local sort 16 bits or fewer).  Otherwise the two scatters take
+ * leading_bits (14..16) bits from bit `shift` up -- of the key, or, windowed, of
+ * (key >> shift) - base -- and the sort inside LDS the local_bits bits [begin_bit, shift).  The
+ * device still refuses at run time if a sub-bucket exceeds 7680 pairs. */
+typedef struct mrs_hybrid_split {
+    int32_t offered;
+    int32_t windowed;
+    uint32_t leading_bits;
+    uint32_t shift;
+    uint32_t base;
+    uint32_t local_bits;
+} mrs_hybrid_split;
+int mrs_hybrid_split_for(uint64_t n, int32_t begin_bit, int32_t end_bit, const uint64_t* window,
+                         mrs_hybrid_split* out);
 #define MRS_SCHEDULE_PASSES 0
 #define MRS_SCHEDULE_MSD 1
 #define MRS_SCHEDULE_MSD_REFUSED 2

@@ -40,6 +40,17 @@ pub struct mrs_dist_desc {
 }
 
 #[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mrs_hybrid_split {
+    pub offered: i32,
+    pub windowed: i32,
+    pub leading_bits: u32,
+    pub shift: u32,
+    pub base: u32,
+    pub local_bits: u32,
+}
+
+#[repr(C)]
 #[derive(Clone, Copy)]
 pub struct mrs_dist_info {
     pub recv_capacity: u64,
@@ -104,6 +115,7 @@ extern "C" {
     pub fn mrs_plan_get_info(plan: *const mrs_plan, info: *mut PlanInfo) -> c_int;
     pub fn mrs_plan_check(plan: *mut mrs_plan, stream: *mut c_void) -> c_int;
     pub fn mrs_plan_get_passes_left_out(plan: *mut mrs_plan, stream: *mut c_void, left_out_mask: *mut u32) -> c_int;
+    pub fn mrs_hybrid_split_for(n: u64, begin_bit: i32, end_bit: i32, window: *const u64, out: *mut mrs_hybrid_split) -> c_int;
     pub fn mrs_plan_get_schedule(plan: *mut mrs_plan, stream: *mut c_void, schedule: *mut i32,
                                  largest_sub_bucket: *mut u32) -> c_int;
     pub fn mrs_plan_set_timing(plan: *mut mrs_plan, enable: c_int) -> c_int;

@@ -177,3 +177,73 @@ def test_built_kernels_have_no_select_on_a_stale_condition_code():
         pytest.skip("no llvm-objdump in this image")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_scc.py"), lib], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def _hybrid_split(lib, n, begin, end, window=None):
+    import ctypes
+
+    out = _lib.HybridSplit()
+    w = (ctypes.c_uint64 * 2)(*window) if window is not None else None
+    rc = lib.mrs_hybrid_split_for(n, begin, end, w, ctypes.byref(out))
+    return rc, out
+
+
+def test_hybrid_split_of_the_whole_key_space():
+    """The host's part of an MRS_ALGO_HYBRID sort (no GPU involved): which inputs are offered the
+    three-move schedule and how the key bits are shared between the two scatters and the local sort."""
+    lib = _lib.load_library()
+    for begin, end in ((0, 30), (0, 32), (3, 29), (0, 25), (7, 32), (0, 31)):
+        width = end - begin
+        for n in (1, 4097, 1 << 22, (1 << 26) - 1, 1 << 26, (1 << 26) + 1, 3 << 25, 1 << 27, (1 << 27) + 12345, 1 << 28,
+                  (1 << 28) + (1 << 26), 6500 << 16, (6500 << 16) + 65536, 1 << 29, (1 << 30) - 1):
+            rc, s = _hybrid_split(lib, n, begin, end)
+            assert rc == _lib.MRS_OK
+            # the local sort takes two digits of at most 8 bits, the scatters 7 or 8 bits each
+            assert 14 <= s.leading_bits <= 16 and s.shift == end - s.leading_bits and not s.windowed and s.base == 0
+            assert s.local_bits == width - s.leading_bits and 9 <= s.local_bits <= 16
+            min_n = (1 << 26) if width <= 30 else ((3 << 25) if width == 31 else (1 << 27))
+            assert bool(s.offered) == (min_n <= n and (n >> 16) <= 6500), (begin, end, n)
+            if s.offered:
+                # evenly spread keys leave sub-buckets a workgroup holds (7680 pairs) with room to spare
+                assert n / (1 << s.leading_bits) <= 6501
+                # and no finer split than needed: the next coarser one would exceed about 5000 pairs
+                if s.leading_bits > max(14, width - 16):
+                    assert n >> (s.leading_bits - 1) > 5120
+    assert _hybrid_split(lib, 1 << 26, 0, 24)[0] == _lib.MRS_ERR_UNSUPPORTED
+    assert _hybrid_split(lib, 1 << 30, 0, 30)[0] == _lib.MRS_ERR_UNSUPPORTED
+    assert _hybrid_split(lib, 0, 0, 30)[0] == _lib.MRS_ERR_UNSUPPORTED
+
+
+def test_hybrid_split_of_a_window():
+    """A piece of the sharded sort: keys between two cut values.  Every key of the window must fall
+    into one of at most 2^leading_bits sub-buckets, evenly spread keys must leave about 5000 pairs
+    or fewer in each, and the local sort must get 16 bits or fewer."""
+    lib = _lib.load_library()
+    rng = np.random.RandomState(5)
+    offered = 0
+    for case in range(4000):
+        end = int(rng.choice([30, 32]))
+        top = (1 << end) - 1
+        n = int(rng.choice([3 << 24, 1 << 26, (1 << 26) + 777, 1 << 27, 1 << 28, 5 << 26]))
+        parts = int(rng.choice([2, 4, 8, 16]))
+        v = int(rng.randint(parts))
+        width = (top + 1) // parts
+        jitter = int(rng.randint(-width // 64, width // 64 + 1))
+        lo = max(0, v * width + (jitter if v else 0))
+        hi = min(top, (v + 1) * width + int(rng.randint(-width // 64, width // 64 + 1))) if v < parts - 1 else top
+        if case % 50 == 0:
+            lo = hi = int(rng.randint(top))  # a run of equal keys
+        rc, s = _hybrid_split(lib, n, 0, end, (lo, hi))
+        assert rc == _lib.MRS_OK
+        if not s.offered:
+            continue
+        offered += 1
+        assert s.windowed and 14 <= s.leading_bits <= 16 and 2 <= s.local_bits <= 16 and s.local_bits == s.shift
+        assert s.base == lo >> s.shift
+        subs = (hi >> s.shift) - s.base + 1
+        assert subs <= 1 << s.leading_bits
+        assert n // subs <= 5120
+    assert offered > 2000
+    # a window so narrow that its keys cannot spread is not offered; nor is one too wide for n
+    assert not _hybrid_split(lib, 1 << 27, 0, 32, (12345, 12345))[1].offered
+    assert not _hybrid_split(lib, 1 << 20, 0, 32, (0, (1 << 32) - 1))[1].offered

@@ -51,6 +51,17 @@ class PlanInfoStruct(ctypes.Structure):
     ]
 
 
+class HybridSplit(ctypes.Structure):
+    _fields_ = [
+        ("offered", ctypes.c_int32),
+        ("windowed", ctypes.c_int32),
+        ("leading_bits", ctypes.c_uint32),
+        ("shift", ctypes.c_uint32),
+        ("base", ctypes.c_uint32),
+        ("local_bits", ctypes.c_uint32),
+    ]
+
+
 class DistDesc(ctypes.Structure):
     _fields_ = [
         ("n_local_max", ctypes.c_uint64),
@@ -95,6 +106,8 @@ SIGNATURES = {
     "mrs_plan_get_info": (ctypes.c_int, [_vp, ctypes.POINTER(PlanInfoStruct)]),
     "mrs_plan_check": (ctypes.c_int, [_vp, _vp]),
     "mrs_plan_get_passes_left_out": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_uint32)]),
+    "mrs_hybrid_split_for": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint64),
+                                            ctypes.POINTER(HybridSplit)]),
     "mrs_plan_get_schedule": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint32)]),
     "mrs_plan_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mrs_plan_get_timings": (ctypes.c_int, [_vp, ctypes.c_int, _fp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),

@@ -754,10 +754,9 @@ static int check_pair_buffers(const mrs_plan* plan, const void* ka, const void* 
 // sub-buckets whatever n is, 2^16 when more than 30 key bits are sorted, and each visit has a
 // latency of its own (measured break-even: 2^25.5 and 2^27 pairs).  MRS_HYBRID_MIN_N: test aid, to
 // run the schedule on inputs a checker can follow.
-static uint64_t hybrid_min_n(const mrs_plan* plan)
+static uint64_t hybrid_min_n(uint32_t width)
 {
     if (const char* e = std::getenv("MRS_HYBRID_MIN_N")) return std::strtoull(e, nullptr, 10);
-    const uint32_t width = plan->desc.end_bit - plan->desc.begin_bit;
     return width <= 30 ? 1ull << 26 : (width == 31 ? 3ull << 25 : 1ull << 27);
 }
 
@@ -765,9 +764,8 @@ static uint64_t hybrid_min_n(const mrs_plan* plan)
 // evenly spread keys (two thirds of what a workgroup holds; fewer, fuller sub-buckets cost the
 // local sort fewer visits), at least 14, and at least so many that 16 bits or fewer are left for
 // the local sort.  A takes the larger half.
-static uint32_t hybrid_msd_bits(const mrs_plan* plan, uint32_t n)
+static uint32_t hybrid_msd_bits(uint32_t width, uint32_t n)
 {
-    const uint32_t width = plan->desc.end_bit - plan->desc.begin_bit;
     uint32_t bits = 14;
     while (bits < 16 && (static_cast<uint64_t>(n) >> bits) > 5120) ++bits;
     // MRS_HYBRID_MSD_BITS: test aid, the finer splits on inputs a checker can follow
@@ -793,10 +791,9 @@ struct HybridSplit {
 // that is a little wider than a power of two needs the next shift, and with it twice the
 // sub-bucket size) and whose local sort gets at most 16 bits.  False when there is none (a window
 // too wide for this n, or so narrow that its keys cannot spread) or the window is empty.
-static bool hybrid_window_split(const mrs_plan* plan, uint32_t n, uint64_t lo, uint64_t hi, HybridSplit* out)
+static bool hybrid_window_split(uint32_t begin, uint32_t n, uint64_t lo, uint64_t hi, HybridSplit* out)
 {
     if (hi < lo || hi > 0xFFFFFFFFull) return false;
-    const uint32_t begin = plan->desc.begin_bit;
     for (uint32_t bits = 14; bits <= 16; ++bits) {
         uint32_t shift = begin + 2;  // the local sort takes two digits of at least one bit
         while (shift < 32 && ((hi >> shift) - (lo >> shift)) >= (1ull << bits)) ++shift;
@@ -807,6 +804,24 @@ static bool hybrid_window_split(const mrs_plan* plan, uint32_t n, uint64_t lo, u
         }
     }
     return false;
+}
+
+// Whether a sort of n pairs on key bits [begin, end) is offered the three-move schedule at all, and
+// with which split.  `window`: null, or two key values every key is known to lie between (the
+// sharded sort's local sorts: keys of one slice of the key space).
+static bool hybrid_choose_split(uint32_t begin, uint32_t end, uint64_t n, const uint64_t* window, HybridSplit* split)
+{
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    if (window) {
+        const char* e = std::getenv("MRS_HYBRID_MIN_N");  // test aid, as in hybrid_min_n
+        const uint64_t min_n = e ? std::strtoull(e, nullptr, 10) : 3ull << 24;  // slices are never exact powers of two
+        return n >= min_n && hybrid_window_split(begin, n32, window[0], window[1], split);
+    }
+    // above about 2^28.7 pairs even evenly spread keys leave sub-buckets a workgroup cannot hold
+    // (6500 on average, 7680 at most): the device would refuse, so it is not asked
+    const uint32_t msd_bits = hybrid_msd_bits(end - begin, n32);
+    *split = HybridSplit{msd_bits, end - msd_bits, 0u, false};
+    return n >= hybrid_min_n(end - begin) && (n >> 16) <= 6500;
 }
 
 // The schedule of an MRS_ALGO_HYBRID plan (mrs_hybrid.hpp): both pass sequences are enqueued and the
@@ -970,18 +985,7 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
     // at 2^28 points)
     if (plan->hybrid) {
         HybridSplit split{};
-        if (window) {
-            // keys of one slice of the key space (the sharded sort's local sorts)
-            const char* e = std::getenv("MRS_HYBRID_MIN_N");  // test aid, as in hybrid_min_n
-            const uint64_t min_n = e ? std::strtoull(e, nullptr, 10) : 3ull << 24;  // slices are never exact powers of two
-            plan->hyb_last = n >= min_n && hybrid_window_split(plan, n32, window[0], window[1], &split);
-        } else {
-            // above about 2^28.7 pairs even evenly spread keys leave sub-buckets a workgroup cannot hold
-            // (6500 on average, 7680 at most): the device would refuse, so it is not asked
-            plan->hyb_last = n >= hybrid_min_n(plan) && (n >> 16) <= 6500;
-            const uint32_t msd_bits = hybrid_msd_bits(plan, n32);
-            split = HybridSplit{msd_bits, plan->desc.end_bit - msd_bits, 0u, false};
-        }
+        plan->hyb_last = hybrid_choose_split(plan->desc.begin_bit, plan->desc.end_bit, n, window, &split);
         if (plan->hyb_last) return sort_pairs_hybrid(plan, n32, keys_a, vals_a, keys_b, vals_b, s, indexed, split);
     }
     // 64-bit keys: passes whose digit is the same for every key are left out on the device
@@ -1056,6 +1060,26 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
         }
     }
     if (plan->desc.algo == MRS_ALGO_ONESWEEP) end_ticketed_call(plan->ctx, s, xcd_block, plan->lineage);
+    return MRS_OK;
+}
+
+extern "C" int mrs_hybrid_split_for(uint64_t n, int32_t begin_bit, int32_t end_bit, const uint64_t* window,
+                                    mrs_hybrid_split* out)
+{
+    clear_error();
+    if (!out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_hybrid_split_for: null output");
+    std::memset(out, 0, sizeof *out);
+    const int width = end_bit - begin_bit;
+    if (begin_bit < 0 || end_bit > 32 || width < 25 || n == 0 || n >= (1ull << 30))
+        return fail(MRS_ERR_UNSUPPORTED, "mrs_hybrid_split_for: MRS_ALGO_HYBRID sorts 25 to 32 bits of a 32-bit key, 0 < n < 2^30");
+    HybridSplit split{};
+    out->offered = hybrid_choose_split(begin_bit, end_bit, n, window, &split) ? 1 : 0;
+    if (!out->offered && window) return MRS_OK;  // no split exists for this window
+    out->leading_bits = split.msd_bits;
+    out->shift = split.shift;
+    out->base = split.base;
+    out->windowed = split.windowed ? 1 : 0;
+    out->local_bits = split.shift - begin_bit;
     return MRS_OK;
 }
 
