@@ -24,7 +24,7 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
     constexpr int THREADS = 1024, UNROLL = 4;
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kHybPackedWords];
     __shared__ int s_diff;
-    __shared__ uint32_t s_stop;
+    __shared__ volatile uint32_t s_stop;  // volatile: polled in the loops with no barrier in between
     const uint32_t tid = threadIdx.x;
     {
         uint4* z = reinterpret_cast<uint4*>(s_cnt);
@@ -545,9 +545,10 @@ int hybrid_launch_pass(bool segmented, bool persistent, bool windowed, int threa
 {
     if (a.wide_status) return fail(MRS_ERR_UNSUPPORTED, "gated passes use 32-bit tile status words");
     if (grid == 0) grid = 1;
-    if (persistent) {  // the plan's ordinary passes: whole array, plain bit-field digits
-        if (segmented || windowed) return fail(MRS_ERR_UNSUPPORTED, "persistent gated passes are plain digit passes");
-        return launch_pass_shape<false, true, kMapNone>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
+    if (persistent) {  // the plan's ordinary passes, or pass B of a sort that shares the device with nothing: plain digits
+        if (windowed) return fail(MRS_ERR_UNSUPPORTED, "persistent gated passes take plain bit-field digits");
+        return segmented ? launch_pass_shape<true, true, kMapNone>(threads, kpt, a, hdr, tables, run_if_mode, grid, s)
+                         : launch_pass_shape<false, true, kMapNone>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
     }
     if (windowed)
         return segmented ? launch_pass_shape<true, false, kMapWindow>(threads, kpt, a, hdr, tables, run_if_mode, grid, s)
