@@ -527,10 +527,13 @@ static int fill_plan(mrs_plan* p, mrs_context* ctx, const mrs_plan_desc* d, cons
                         "n < 2^30, tile_items 0, 4096 or 32768",
                         who);
         resolved.algo = MRS_ALGO_ONESWEEP;
-        if (resolved.tile_items == 0) resolved.tile_items = d->n >= (1ull << 20) ? 32768 : 4096;
         // ranking by returning LDS atomics is all the gated kernels are built for; a device that
-        // failed the lane-order check gets the plain chained-scan plan
-        hybrid = ctx->lds_atomics_in_lane_order && !std::getenv("MRS_FORCE_WIDE_STATUS");
+        // failed the lane-order check gets the plain chained-scan plan, and so does a plan too small
+        // ever to be offered the schedule (below 3 * 2^24 pairs; MRS_HYBRID_MIN_N, the test aid, lifts that)
+        hybrid = ctx->lds_atomics_in_lane_order && !std::getenv("MRS_FORCE_WIDE_STATUS") &&
+                 (d->n >= (3ull << 24) || std::getenv("MRS_HYBRID_MIN_N"));
+        // the gated kernels exist for two tile shapes
+        if (hybrid && resolved.tile_items == 0) resolved.tile_items = d->n >= (1ull << 20) ? 32768 : 4096;
         d = &resolved;
     }
     KernelConfig cfg;
