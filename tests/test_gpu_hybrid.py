@@ -307,3 +307,34 @@ def test_primed_call_on_a_hybrid_plan(ctx, oracle, mrs, small_inputs_take_the_sc
     rk, rv = oracle.stable_sort_pairs(hk, hv, n, 1, 1, 0, 30)
     assert np.array_equal(to_u32(keys), rk) and np.array_equal(to_u32(idx), rv)
     plan.close()
+
+
+@pytest.mark.parametrize("tile,log2n", [(4096, 20), (32768, 23)])
+def test_buckets_of_exactly_one_full_tile(ctx, oracle, mrs, small_inputs_take_the_schedule, monkeypatch, tile, log2n):
+    """Every first-level bucket holds exactly one full tile of pass B (no partial tile anywhere, every
+    tile the first and only one of its chain), in shuffled and in sorted input order."""
+    monkeypatch.setenv("MRS_HYBRID_MSD_BITS", "16")
+    n = 1 << log2n
+    assert n // 256 == tile
+    base = (np.arange(n, dtype=np.uint64) << np.uint64(32 - log2n)).astype(np.uint32)  # n distinct keys, evenly spaced
+    for order in ("sorted", "shuffled"):
+        keys = base if order == "sorted" else np.ascontiguousarray(base[np.random.RandomState(1).permutation(n)])
+        vals = make_vals(oracle, n, 1)
+        ko, vo, in_b, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 0, 32, tile_items=tile)
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD and largest == n >> 16 and not in_b
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+        assert np.array_equal(ko, rk) and np.array_equal(vo, rv), order
+
+
+def test_empty_buckets_between_full_ones(ctx, oracle, mrs, small_inputs_take_the_schedule):
+    """Only 3 of the 256 first-level buckets hold keys (one of them the last), and inside them only
+    every other sub-bucket: pass B's tile table has runs of empty buckets, the local sort empty visits."""
+    n = 250001
+    r = oracle.gen_u32(21, 4, n)
+    top = np.array([3, 200, 255], dtype=np.uint32)[oracle.gen_u32(21, 5, n) % 3]
+    keys = (top << np.uint32(24)) | (r & np.uint32(0x00FEFFFF))  # bit 16 clear: odd sub-buckets stay empty
+    vals = make_vals(oracle, n, 1)
+    ko, vo, in_b, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 0, 32)
+    assert schedule == mrs.SortPlan.SCHEDULE_MSD and 0 < largest <= 7680 and not in_b
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
