@@ -165,6 +165,11 @@ struct DeviceActivity {
     // events even where they use two streams, and count as one stream here.
     const void* lineage = nullptr;
     bool recorded = false;
+    // A call that took die-aware tickets and is still being enqueued by its host thread: its event
+    // does not exist yet, so a call that begins on another thread meanwhile goes by these.
+    int open = 0;
+    hipStream_t open_stream = nullptr;
+    const void* open_lineage = nullptr;
 };
 static DeviceActivity g_activity[kMaxDevices];
 
@@ -209,30 +214,40 @@ static uint32_t xcd_block_tiles(const mrs_context* ctx)
 }
 
 // Ticket block size for the chained-scan passes of one call on stream `s`: the context's, unless
-// a die-aware call on another stream of this device may still be running (DeviceActivity).
+// a die-aware call on another stream of this device may still be running or is being enqueued by
+// another thread right now (DeviceActivity).  `*counted` is set when the call was entered in
+// DeviceActivity::open and end_ticketed_call has to take it out again.
 // Under stream capture nothing can be queried: the captured work keeps the context's setting,
 // and replays that overlap on one device are the caller's to avoid.
-static uint32_t begin_ticketed_call(const mrs_context* ctx, hipStream_t s, const void* lineage)
+static uint32_t begin_ticketed_call(const mrs_context* ctx, hipStream_t s, const void* lineage, bool* counted)
 {
+    *counted = false;
     uint32_t block = xcd_block_tiles(ctx);
     if (block == 0 || stream_is_capturing(s)) return block;
     DeviceActivity& a = g_activity[ctx->device];
     std::lock_guard<std::mutex> lock(a.m);
-    const bool same_order = a.stream == s || (lineage && lineage == a.lineage);
-    if (a.recorded && !same_order && a.event) {
-        if (hipEventQuery(a.event) != hipSuccess) block = 0;
+    bool other = false;
+    if (a.open > 0 && !(a.open_stream == s || (lineage && lineage == a.open_lineage))) other = true;
+    if (!other && a.recorded && a.event && !(a.stream == s || (lineage && lineage == a.lineage))) {
+        if (hipEventQuery(a.event) != hipSuccess) other = true;
         (void)hipGetLastError();  // "not ready" is an answer, not an error to report later
     }
+    if (other) return 0;
+    ++a.open;
+    a.open_stream = s;
+    a.open_lineage = lineage;
+    *counted = true;
     return block;
 }
 
 // Leaves the mark the next call looks for.  Only calls that did use die-aware tickets need one.
-static void end_ticketed_call(const mrs_context* ctx, hipStream_t s, uint32_t block, const void* lineage)
+static void end_ticketed_call(const mrs_context* ctx, hipStream_t s, uint32_t block, const void* lineage, bool counted)
 {
-    if (block == 0 || stream_is_capturing(s)) return;
+    if (!counted) return;
     DeviceActivity& a = g_activity[ctx->device];
     std::lock_guard<std::mutex> lock(a.m);
-    if (!a.event) return;
+    if (a.open > 0) --a.open;
+    if (block == 0 || !a.event) return;
     if (hipEventRecord(a.event, s) == hipSuccess) {
         a.stream = s;
         a.lineage = lineage;
@@ -241,6 +256,28 @@ static void end_ticketed_call(const mrs_context* ctx, hipStream_t s, uint32_t bl
         (void)hipGetLastError();
     }
 }
+
+// One call's worth of the two functions above: whatever way the call is left, the entry in
+// DeviceActivity::open goes with it and the event is recorded behind what was enqueued.
+class TicketedCall {
+public:
+    TicketedCall(const mrs_context* ctx, hipStream_t s, const void* lineage, bool chained_scan = true)
+        : ctx_(ctx), s_(s), lineage_(lineage)
+    {
+        if (chained_scan) block_ = begin_ticketed_call(ctx, s, lineage, &counted_);
+    }
+    ~TicketedCall() { end_ticketed_call(ctx_, s_, block_, lineage_, counted_); }
+    TicketedCall(const TicketedCall&) = delete;
+    TicketedCall& operator=(const TicketedCall&) = delete;
+    uint32_t block() const { return block_; }
+
+private:
+    const mrs_context* ctx_;
+    hipStream_t s_;
+    const void* lineage_;
+    uint32_t block_ = 0;
+    bool counted_ = false;
+};
 
 // A stream that is about to be destroyed must not stay behind as "where the last die-aware call
 // ran": the next call would query an event whose stream is gone.  Waits for the stream first.
@@ -646,7 +683,10 @@ extern "C" int mrs_plan_create(mrs_context* ctx, const mrs_plan_desc* d, mrs_pla
             return fail(MRS_ERR_OUT_OF_MEMORY, "mrs_plan_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         }
         bind_onesweep_memory(p, temp);
+        // The first sort may run on a stream that does not wait for the null stream: the fill must
+        // have finished, not merely been queued, before the plan is handed out.
         e = hipMemset(p->temp, 0, bytes);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess) {
             (void)hipFree(p->temp);
             delete p;
@@ -833,7 +873,8 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
                              hipStream_t s, bool indexed, const HybridSplit& split)
 {
     const uint32_t num_tiles = (n32 + plan->tile_items - 1) / plan->tile_items;
-    const uint32_t xcd_block = begin_ticketed_call(plan->ctx, s, plan->lineage);
+    const TicketedCall ticketed(plan->ctx, s, plan->lineage);
+    const uint32_t xcd_block = ticketed.block();
     const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
     const size_t zero = static_cast<size_t>(plan->status - plan->zero_begin) + status_bytes(plan, num_tiles);
     if (int rc = clear_async(plan->zero_begin, zero, s)) return rc;
@@ -942,7 +983,6 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
             return rc;
         if (int rc = mark(plan, "fallback_pass", s)) return rc;
     }
-    end_ticketed_call(plan->ctx, s, xcd_block, plan->lineage);
     return MRS_OK;
 }
 
@@ -1002,9 +1042,9 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
     static const bool no_pass_skip = std::getenv("MRS_NO_PASS_SKIP") != nullptr;
     const bool skip_passes = plan->desc.algo == MRS_ALGO_ONESWEEP && plan->desc.key_words == 2 && !no_pass_skip;
     plan->pass_plan_live = skip_passes;
-    uint32_t xcd_block = 0;
+    const TicketedCall ticketed(plan->ctx, s, plan->lineage, plan->desc.algo == MRS_ALGO_ONESWEEP);
+    const uint32_t xcd_block = ticketed.block();
     if (plan->desc.algo == MRS_ALGO_ONESWEEP) {
-        xcd_block = begin_ticketed_call(plan->ctx, s, plan->lineage);
         const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
         const size_t zero = static_cast<size_t>(plan->status - plan->zero_begin) + align_up(region * plan->num_passes, 256);
         // a primed plan keeps its histograms: only the ticket counters and the status words are cleared
@@ -1068,7 +1108,6 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
             if (int rc = mark(plan, "onesweep_pass", s)) return rc;
         }
     }
-    if (plan->desc.algo == MRS_ALGO_ONESWEEP) end_ticketed_call(plan->ctx, s, xcd_block, plan->lineage);
     return MRS_OK;
 }
 
@@ -1397,10 +1436,10 @@ int partition_pass(mrs_plan* plan, uint64_t n, const void* keys_in, const void* 
     a.status = plan->status;
     a.wide_status = plan->status_word_bytes == 8;
     a.tile_counter = plan->control->tile_counter[0];
-    a.xcd_block = begin_ticketed_call(plan->ctx, s, plan->lineage);
+    const TicketedCall ticketed(plan->ctx, s, plan->lineage);
+    a.xcd_block = ticketed.block();
     a.error_flag = plan->error_flag;
     if (int rc = launch_pass(plan, kModeOnesweep, a, s)) return rc;
-    end_ticketed_call(plan->ctx, s, a.xcd_block, plan->lineage);
     return MRS_OK;
 }
 
