@@ -280,3 +280,49 @@ def test_sharded_sort_ranks_on_one_gpu_large(ctx, mrs, world, log2n, dist_name):
         if want is not None:
             assert all(int(o[2].last_sort_schedule[c]) in want for o in outs for c in range(2)), \
                 [list(o[2].last_sort_schedule) for o in outs]
+
+
+def test_first_sorts_of_in_process_ranks_never_starve(mrs):
+    """Eight in-process ranks leave their host-side collectives together, so their partition passes
+    and local sorts begin within microseconds of each other on one device.  Only one sort per
+    device may deal its tiles per die at a time (two can each hold the compute units the other
+    waits for); a second call that begins while the first is still being enqueued must see it.
+    When it did not, about one first sort in 40 of fresh handles ended in the look-back time-out,
+    which the handle's check reports.  60 fresh sets of handles, one sort each, every key inside
+    one bucket of the first split."""
+    import threading
+
+    from wgpu_morton_code_radix_sort_test_amd.dist import Communicator, DistributedSorter
+
+    world, n = 8, 1 << 24
+    for rep in range(60):
+        comms = Communicator.local(world)
+        errors, got = [], [0] * world
+
+        def body(r):
+            try:
+                torch.cuda.set_device(0)
+                c = mrs.Context(0)
+                stream = torch.cuda.Stream()
+                with torch.cuda.stream(stream):
+                    keys = c.generate_u32(3 + r + 10 * rep, 1, n, stream=stream)
+                    keys &= 0x3FFFF
+                    keys |= 0x3A500000
+                    idx = torch.arange(r * n, (r + 1) * n, dtype=torch.int32, device=c.device)
+                    sorter = DistributedSorter(c, comms[r], n, end_bit=30)
+                    ok, _ = sorter.sort(keys, idx, stream=stream)
+                    sorter.check(stream=stream)
+                    k64 = ok.to(torch.int64)
+                    assert bool((k64[1:] >= k64[:-1]).all())
+                    got[r] = int(ok.numel())
+                    sorter.close()
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        [c.close() for c in comms]
+        if errors:
+            raise AssertionError(f"fresh set {rep}: {errors[0]}")
+        assert sum(got) == world * n
