@@ -15,10 +15,14 @@ unsorted buffer from a pool built beforehand (sorting mutates its input, and
 re-sorting sorted data would be a different workload), so the timed region
 holds nothing but the K sorts.
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) a step is the
-sharded sort of N * 2^28 pairs, one mrs_dist_sort_pairs call per rank: top-digit
-histogram, RCCL all-reduce + all-gather, splitter, local partition pass,
-all-to-all-v exchange over xGMI, local sort (weak scaling: 2^31 pairs at N = 8).
+With N > 1 a step is the sharded sort of 2^31 pairs in all, 2^31 / N per GPU (strong scaling: the
+metric's curve is quoted on 2^31 keys; `--log2n L` fixes 2^L pairs per GPU instead, weak scaling),
+one mrs_dist_sort_pairs call per rank: top-digit histogram, RCCL all-reduce + all-gather,
+splitter, local partition pass, all-to-all-v exchange over xGMI, local sort.  The ranks are
+one process per GPU: either torch.distributed.run started them (RANK / WORLD_SIZE set), or this
+script does so itself when called as `python bench.py --gpus N` -- the parent then only spawns
+`python -m torch.distributed.run ... bench.py` and passes on its exit status, without ever
+touching the GPU.  `n_gpus` in the line is the world the communicator reports.
 
 Rank 0 prints one JSON line.  `value` is whole-job Gkeys/s.  `roofline` is for
 the dominant kernel (the chained-scan digit pass: 16 algorithmic bytes per pair per
@@ -34,12 +38,14 @@ import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import wgpu_morton_code_radix_sort_test_amd as mrs  # noqa: E402
+# torch and the library are imported by the ranks only (load_modules): the process that merely
+# starts the ranks must not touch the GPU, nor map libmrs.so
+torch = None
+mrs = None
 
 HBM_PEAK_BYTES_PER_S = 8.0e12          # MI355X HBM3E peak
 SORT_BYTES_PER_PAIR = 68.0             # 4 (key read for histograms) + 4 passes * (8 read + 8 write)
@@ -47,12 +53,14 @@ PASS_BYTES_PER_PAIR = 16.0             # one digit pass: read key+index, write k
 SEED = 7
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2n", type=int, default=28, help="pairs per GPU = 2^log2n")
+    ap.add_argument("--log2n", type=int, default=None,
+                    help="pairs per GPU = 2^log2n (default: 28 on one GPU; with N > 1 GPUs 2^31 / N, the fixed total the "
+                         "metric's curve is quoted on)")
     ap.add_argument("--algo", default="hybrid", choices=["hybrid", "onesweep", "three_kernel"])
     ap.add_argument("--end-bit", type=int, default=0,
                     help="one past the last key bit sorted on (0: 30 for --algo hybrid, whose keys are 30-bit codes, else 32)")
@@ -63,7 +71,58 @@ def parse_args():
     ap.add_argument("--cpu-sample-log2", type=int, default=0, help="pairs of the parallel CPU sort = 2^this (0 = the whole step input)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the 2^30-pair leg")
-    return ap.parse_args()
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="every rank prints its RANK / WORLD_SIZE / pairs per GPU as one JSON line and exits "
+                         "without touching the GPU or the library (checks the rank launcher)")
+    return ap.parse_args(argv)
+
+
+TOTAL_PAIRS_CURVE = 1 << 31   # the metric's 1/2/4/8-GPU curve is quoted on 2^31 keys in all
+
+
+def pairs_per_gpu(log2n, world):
+    """(pairs each rank holds, "weak" | "strong").  --log2n fixes the per-GPU size (weak scaling);
+    without it one GPU sorts the headline 2^28 pairs and N > 1 GPUs share 2^31 (strong scaling)."""
+    if log2n is not None:
+        return 1 << log2n, "weak"
+    if world <= 1:
+        return 1 << 28, "weak"
+    return TOTAL_PAIRS_CURVE // world, "strong"
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N ranks of this script as
+    child processes, one per GPU, and return their exit status.  Nothing here touches the GPU,
+    imports torch or maps libmrs.so: a process that has initialised the GPU must not be the one
+    that execs or forks the ranks.  Rank 0's JSON line reaches stdout through the inherited pipe."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    rc = subprocess.run(cmd, env=env).returncode
+    if args.launch_selftest:
+        print(json.dumps({"selftest_parent": True, "children_status": rc, "torch_imported": "torch" in sys.modules,
+                          "library_imported": "wgpu_morton_code_radix_sort_test_amd" in sys.modules}), flush=True)
+    return rc
+
+
+def size_label(n):
+    return f"2^{n.bit_length() - 1}" if n & (n - 1) == 0 else str(n)
+
+
+def load_modules():
+    global torch, mrs
+    import torch as _torch
+
+    import wgpu_morton_code_radix_sort_test_amd as _mrs
+
+    torch, mrs = _torch, _mrs
 
 
 def make_input(ctx, n, seed):
@@ -170,10 +229,21 @@ def load_traffic():
 
 
 def main():
-    args = parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: this process only starts the ranks
+        raise SystemExit(launch_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    n, scaling = pairs_per_gpu(args.log2n, world)
+    if args.launch_selftest:
+        print(json.dumps({"selftest": True, "rank": rank, "local_rank": local_rank, "world": world, "pairs_per_gpu": n,
+                          "scaling": scaling, "torch_imported": "torch" in sys.modules,
+                          "library_imported": "wgpu_morton_code_radix_sort_test_amd" in sys.modules}), flush=True)
+        return
+    load_modules()
     # MRS_BENCH_FORCE_DIST=1 runs the sharded path with a single rank (rehearsal on a one-GPU box)
     distributed = world > 1 or os.environ.get("MRS_BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
@@ -187,7 +257,6 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = mrs.Context(local_rank)
-    n = 1 << args.log2n
     algo = {"hybrid": mrs.ALGO_HYBRID, "onesweep": mrs.ALGO_ONESWEEP}.get(args.algo, mrs.ALGO_THREE_KERNEL)
     end_bit = args.end_bit or (30 if algo == mrs.ALGO_HYBRID else 32)
 
@@ -342,6 +411,8 @@ def main():
             sweep = {}
             for label, log2m, eb in (("2^26", 26, 30), ("2^27", 27, 30), ("2^28 refused", 28, 32)):
                 m = 1 << log2m
+                if m > n:  # the ping-pong buffers are the headline's
+                    continue
                 p2 = mrs.SortPlan(ctx, m, key_words=1, payload_bytes=4, digit_bits=8, end_bit=eb, algo=mrs.ALGO_HYBRID)
                 p2.set_timing(True)
                 k2, i2 = make_input(ctx, m, SEED + 900 + log2m)
@@ -410,8 +481,10 @@ def main():
         breakdown = sorter.last_breakdown()
         sorter.set_timing(False)
         if breakdown.get("dist_local_sort_passes") and rank == 0:
+            # the timed launches are the digit passes of the LAST piece of rank 0's share only
             avg_pass = breakdown["dist_local_sort_pass_ms"] * 1e-3
-            achieved = PASS_BYTES_PER_PAIR * sorter.n_out / avg_pass / 1e9
+            piece_pairs = breakdown["dist_local_sort_piece_pairs"]
+            achieved = PASS_BYTES_PER_PAIR * piece_pairs / avg_pass / 1e9
             roofline = {
                 "bound": "hbm",
                 "kernel": "the chained-scan digit pass (local sort of rank 0: " + ", ".join(breakdown.get("dist_local_sort_schedule", [])) + ")",
@@ -420,7 +493,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S,
                 "traffic": None,
-                "algorithmic_bytes_per_launch": PASS_BYTES_PER_PAIR * sorter.n_out,
+                "algorithmic_bytes_per_launch": PASS_BYTES_PER_PAIR * piece_pairs,
                 "avg_launch_ms": avg_pass * 1e3,
             }
         if world > 1:
@@ -438,7 +511,7 @@ def main():
 
     c4 = None
     c5_one_gpu = None
-    if rank == 0 and not distributed and not args.no_c4 and algo in (mrs.ALGO_ONESWEEP, mrs.ALGO_HYBRID) and args.log2n == 28:
+    if rank == 0 and not distributed and not args.no_c4 and algo in (mrs.ALGO_ONESWEEP, mrs.ALGO_HYBRID) and n == (1 << 28):
         # free the pool first: the 2^30 leg wants about 45 GiB
         del inputs, kb, vb, out
         if restore:
@@ -460,17 +533,18 @@ def main():
             "metric": "Gkeys/s sorted (u32 Morton key + u32 payload)",
             "value": value,
             "unit": "Gkeys/s",
-            "n_gpus": world,
+            "n_gpus": comm.world if distributed else 1,  # what the communicator reports, not the argument
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"2^{args.log2n} (30-bit Morton key, u32 index) pairs per GPU from uniform random 3D points, "
+                "workload": f"{size_label(n)} (30-bit Morton key, u32 index) pairs per GPU"
+                            + (f" ({size_label(total_pairs)} in all)" if world > 1 else "") + " from uniform random 3D points, "
                             + (f"key bits [0, 30), local sorts by the three-move schedule over each piece's window of the key space (four 8-bit passes where the device refuses it)" if distributed else
                                f"{args.digit_bits}-bit digits over key bits [0, {end_bit}), {args.algo}"),
                 "pairs_per_gpu": n,

@@ -397,6 +397,9 @@ typedef struct mrs_dist_info {
     uint32_t last_sort_passes;
     uint32_t last_sort_schedule[2]; /* MRS_SCHEDULE_* of the local sort of each piece of the last call
                                        (mrs_dist_get_info waits for the device to read them)            */
+    uint64_t last_sort_piece_pairs; /* pairs of the piece whose digit passes last_sort_pass_ms times: the
+                                       LAST piece of the rank's share (about last_n_out / exchange_chunks),
+                                       so bytes per launch = 16 * this, not 16 * last_n_out             */
 } mrs_dist_info;
 
 int mrs_dist_create(mrs_context* ctx, mrs_comm* comm, const mrs_dist_desc* desc, mrs_dist** out);

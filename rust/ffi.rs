@@ -62,6 +62,7 @@ pub struct mrs_dist_info {
     pub last_sort_pass_ms: f32,
     pub last_sort_passes: u32,
     pub last_sort_schedule: [u32; 2],
+    pub last_sort_piece_pairs: u64,
 }
 
 #[repr(C)]

@@ -84,6 +84,7 @@ class DistInfoStruct(ctypes.Structure):
         ("last_sort_pass_ms", ctypes.c_float),
         ("last_sort_passes", ctypes.c_uint32),
         ("last_sort_schedule", ctypes.c_uint32 * 2),
+        ("last_sort_piece_pairs", ctypes.c_uint64),
     ]
 
 

@@ -389,6 +389,7 @@ struct mrs_dist {
     bool marks_valid = false;
     uint32_t last_levels = 0, last_exact_cuts = 0;
     uint64_t last_n_out = 0;
+    uint64_t last_piece_pairs = 0;  // pairs of the last piece (the one whose plan records timings)
 };
 
 using namespace mrs;
@@ -636,6 +637,7 @@ extern "C" int mrs_dist_get_info(mrs_dist* dist, mrs_dist_info* info)
     info->last_levels = dist->last_levels;
     info->last_exact_cuts = dist->last_exact_cuts;
     info->last_n_out = dist->last_n_out;
+    info->last_sort_piece_pairs = dist->last_piece_pairs;
     {
         // what the device chose is in device memory: wait for everything this rank enqueued
         MRS_HIP_TRY(hipDeviceSynchronize());
@@ -824,6 +826,7 @@ extern "C" int mrs_dist_sort_pairs(mrs_dist* dist, uint64_t n_local, const void*
             ro += recv_cnt[p];
         }
         const uint64_t piece = ro - region;
+        if (c == K - 1) d->last_piece_pairs = piece;
         ExchangeArrays x{};
         x.send[0] = send_k;
         x.recv[0] = d->recv_k;

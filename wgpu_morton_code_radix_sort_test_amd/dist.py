@@ -135,6 +135,7 @@ class DistributedSorter:
             "dist_exact_cuts": int(i.last_exact_cuts),
             "dist_local_sort_pass_ms": float(i.last_sort_pass_ms),
             "dist_local_sort_passes": int(i.last_sort_passes),
+            "dist_local_sort_piece_pairs": int(i.last_sort_piece_pairs),
             "dist_local_sort_schedule": [{0: "passes", 1: "msd", 2: "msd refused by the device"}[int(x)]
                                          for x in i.last_sort_schedule],
         }
