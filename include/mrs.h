@@ -111,14 +111,37 @@ int mrs_context_destroy(mrs_context* ctx);
 #define MRS_ATTR_COMPUTE_UNITS 0 /* compute units of the device                               */
 #define MRS_ATTR_RANK_MODE 1     /* how digit passes rank keys inside a wave: 0 = ballot
                                     matching, 1 = returning LDS atomics (chosen by a device
-                                    check at creation; MRS_RANK=match in the environment
-                                    selects 0)                                                  */
+                                    check at creation; can be set to 0, and back to 1 where
+                                    the check passed)                                           */
 #define MRS_ATTR_DIE_AWARE_TICKETS 2 /* 1 if a large grid was seen to land on all 8 dies (XCDs) in
                                     comparable shares: onesweep passes then hand blocks of
                                     consecutive tiles to workgroups of one die               */
 #define MRS_ATTR_NOALLOC_TIMEOUT 3 /* synchronises the device; 1 if a chained-scan workgroup of an
                                     mrs_sort_pairs_noalloc call gave up waiting since the last
                                     query (that call's output is invalid); reading clears it     */
+/* Range markers for an external profiler, the counterpart of the reference's named compute passes
+ * (src/main.rs:583-662).  1: every launch a sort or encode call of THIS PROCESS enqueues is
+ * bracketed by a roctx range (roctxRangePush/Pop, bound at run time from
+ * librocprofiler-sdk-roctx.so or libroctx64.so) named as the reference names the pass it stands
+ * for: "Morton Coding", "Histogram calculation", "Large Prefix Sum part 1", "Small Prefix Sum",
+ * "Large Prefix Sum part 2", "Indexing"; launches without a counterpart there are named for what
+ * they do ("Clear", "Local sort", "Gather").  `rocprofv3 --marker-trace --kernel-trace` then reads
+ * like the reference's NSight capture.  Setting it fails with MRS_ERR_UNSUPPORTED if no roctx
+ * library can be loaded. */
+#define MRS_ATTR_ROCTX_RANGES 4
+/* Aids for tests and A/B runs.  A plan copies them from its context WHEN IT IS CREATED; sort calls
+ * never look at the context or the environment again.  All default to 0. */
+#define MRS_ATTR_TEST_HYBRID_MIN_N 5          /* MRS_ALGO_HYBRID plans offer the three-move schedule from
+                                                 this many pairs on (default: 2^26 .. 2^27 by key width),
+                                                 so that it runs on inputs a checker can follow          */
+#define MRS_ATTR_TEST_HYBRID_LEADING_BITS 6   /* 14..16: bits the two scatters of that schedule take     */
+#define MRS_ATTR_TEST_HYBRID_FORCE_FALLBACK 7 /* 1: the device takes the plan's ordinary passes whatever
+                                                 the keys are                                            */
+#define MRS_ATTR_TEST_NO_SMALL_SORT 8         /* 1: inputs of at most 4096 elements take the general
+                                                 multi-launch path, not the one-workgroup sort          */
+#define MRS_ATTR_TEST_NO_PASS_SKIP 9          /* 1: 64-bit keys run every pass (src/main.rs:594-665)     */
+#define MRS_ATTR_TEST_WIDE_STATUS 10          /* 1: chained-scan plans use the 64-bit tile status words
+                                                 of inputs above 2^30 elements at any size              */
 int mrs_context_get_attribute(const mrs_context* ctx, int attribute, int64_t* value);
 /* MRS_ATTR_DIE_AWARE_TICKETS can be cleared (value 0) and, where the creation-time check passed,
  * set again.  With die-aware tickets a pass makes progress only if it keeps getting workgroup

@@ -29,3 +29,18 @@ def ctx():
     import wgpu_morton_code_radix_sort_test_amd as mrs
 
     return mrs.Context(0)
+
+
+@pytest.fixture()
+def aids(ctx):
+    """Setter for the MRS_ATTR_TEST_* attributes of the shared context: `aids(which, value)`.  A plan
+    copies them when it is created; everything set is put back to 0 when the test ends."""
+    touched = []
+
+    def set_(which, value):
+        ctx.set_attribute(which, value)
+        touched.append(which)
+
+    yield set_
+    for which in touched:
+        ctx.set_attribute(which, 0)

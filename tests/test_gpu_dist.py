@@ -52,7 +52,7 @@ def rank_keys(oracle, n, key_words, dist, seed, end_bit):
     return k.reshape(-1)
 
 
-def run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, tolerance, rounds=1, chunks=0):
+def run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, tolerance, rounds=1, chunks=0, hybrid_min_n=0):
     """One thread per rank on GPU 0; returns per-rank (keys, payload) numpy arrays and infos."""
     from wgpu_morton_code_radix_sort_test_amd.dist import Communicator, DistributedSorter
 
@@ -64,6 +64,7 @@ def run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, tolerance, round
         try:
             torch.cuda.set_device(0)
             ctx = mrs.Context(0)
+            ctx.set_attribute(ctx.ATTR_TEST_HYBRID_MIN_N, hybrid_min_n)  # read by the plans the handle creates
             stream = torch.cuda.Stream()
             n = sizes[r]
             with torch.cuda.stream(stream):
@@ -173,19 +174,18 @@ WINDOW_CASES = [
 
 
 @pytest.mark.parametrize("world,end_bit,dist,chunks,want", WINDOW_CASES)
-def test_local_sorts_take_the_three_move_schedule(oracle, mrs, monkeypatch, world, end_bit, dist, chunks, want):
+def test_local_sorts_take_the_three_move_schedule(oracle, mrs, world, end_bit, dist, chunks, want):
     """The local sorts of (u32 key, u32 payload) slices are MRS_ALGO_HYBRID plans whose sub-buckets
     divide the slice's window of the key space (the cut keys on either side).  The library keeps
     pieces below 2^26 pairs on the ordinary passes, so the test lowers that threshold; the result
     must be the one stable sort of the concatenated input whatever the device decides per piece."""
-    monkeypatch.setenv("MRS_HYBRID_MIN_N", "1")
     rng = np.random.default_rng(world * 11 + end_bit)
     sizes = [int(rng.integers(30000, 120000)) for _ in range(world)]
     if world == 3:
         sizes[1] = 0
         sizes[2] = 4097
     host_keys = [rank_keys(oracle, n, 1, dist, seed=17 * r + 3, end_bit=end_bit) for r, n in enumerate(sizes)]
-    results, infos = run_ranks(mrs, world, sizes, host_keys, 1, end_bit, 0, chunks=chunks)
+    results, infos = run_ranks(mrs, world, sizes, host_keys, 1, end_bit, 0, chunks=chunks, hybrid_min_n=1)
     check_against_oracle(oracle, results, host_keys, sizes, 1, end_bit, max(sizes) // 256)
     pieces = chunks or (2 if 2 <= world <= 8 else 1)
     seen = {int(i.last_sort_schedule[c]) for i in infos for c in range(pieces)}
@@ -196,7 +196,8 @@ def test_local_sorts_take_the_three_move_schedule(oracle, mrs, monkeypatch, worl
 def test_local_ranks_fuzz(oracle, mrs):
     """Seeded random shapes of the sharded sort: rank count, slice sizes (empty and tiny slices
     included), key width and live bits, distribution, tolerance and pieces per rank drawn together.
-    MRS_DIST_FUZZ_CASES / MRS_DIST_FUZZ_SEED widen a run."""
+    MRS_DIST_FUZZ_CASES / MRS_DIST_FUZZ_SEED widen a run; MRS_DIST_FUZZ_HYBRID_MIN_N=1 lets the local sorts of
+    these small pieces take the three-move schedule."""
     import os
 
     rng = np.random.default_rng(int(os.environ.get("MRS_DIST_FUZZ_SEED", "5")))
@@ -217,7 +218,7 @@ def test_local_ranks_fuzz(oracle, mrs):
         what = (case, world, key_words, end_bit, dist, sizes, chunks, tolerance)
         try:
             results, _ = run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, 0 if tolerance is None else tolerance,
-                                   chunks=chunks)
+                                   chunks=chunks, hybrid_min_n=int(os.environ.get("MRS_DIST_FUZZ_HYBRID_MIN_N", "0")))
             check_against_oracle(oracle, results, host_keys, sizes, key_words, end_bit, max(tol, 1))
         except AssertionError as exc:
             raise AssertionError(f"{what}: {exc}") from exc

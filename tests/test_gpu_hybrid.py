@@ -21,10 +21,10 @@ def mrs():
 
 
 @pytest.fixture()
-def small_inputs_take_the_schedule(monkeypatch):
-    """The library keeps inputs below 2^22 pairs on the ordinary passes; the checker is too slow
-    for more, so the tests lower the threshold (read by the library at every sort call)."""
-    monkeypatch.setenv("MRS_HYBRID_MIN_N", "1")
+def small_inputs_take_the_schedule(ctx, aids):
+    """The library keeps inputs below 2^26 pairs on the ordinary passes; the checker is too slow
+    for more, so the tests lower the threshold (a plan reads it from its context at creation)."""
+    aids(ctx.ATTR_TEST_HYBRID_MIN_N, 1)
 
 
 def _sort_with_plan(ctx, mrs, keys, vals, n, begin, end, capacity=None, tile_items=0, indexed=False):
@@ -100,10 +100,10 @@ def test_sub_buckets_at_the_capacity(ctx, oracle, mrs, small_inputs_take_the_sch
 
 @pytest.mark.parametrize("msd_bits", [14, 15, 16])
 @pytest.mark.parametrize("begin,end", [(0, 25), (0, 27), (3, 29), (2, 32), (7, 32), (0, 31), (0, 30)])
-def test_bit_ranges(ctx, oracle, mrs, small_inputs_take_the_schedule, monkeypatch, begin, end, msd_bits):
+def test_bit_ranges(ctx, oracle, mrs, small_inputs_take_the_schedule, aids, begin, end, msd_bits):
     """Bits outside [begin, end) are carried along untouched and never compared; every split of the
     leading bits between the two scatters (7 + 7, 8 + 7, 8 + 8; the library picks it from n)."""
-    monkeypatch.setenv("MRS_HYBRID_MSD_BITS", str(msd_bits))
+    aids(ctx.ATTR_TEST_HYBRID_LEADING_BITS, msd_bits)
     n = 150001
     keys = make_keys(oracle, n, 1, "random", seed=end * 32 + begin)
     vals = make_vals(oracle, n, 1)
@@ -113,10 +113,10 @@ def test_bit_ranges(ctx, oracle, mrs, small_inputs_take_the_schedule, monkeypatc
     assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
 
 
-def test_device_refusal_can_be_forced(ctx, oracle, mrs, small_inputs_take_the_schedule, monkeypatch):
+def test_device_refusal_can_be_forced(ctx, oracle, mrs, small_inputs_take_the_schedule, aids):
     """The gated ordinary passes (persistent workgroups drawing tiles) on keys that would have taken
     the new schedule."""
-    monkeypatch.setenv("MRS_HYBRID_FORCE_FALLBACK", "1")
+    aids(ctx.ATTR_TEST_HYBRID_FORCE_FALLBACK, 1)
     for n in (4097, 70001, 300000, (1 << 20) + 5):
         keys = make_keys(oracle, n, 1, "morton30", seed=n)
         vals = make_vals(oracle, n, 1)
@@ -310,10 +310,10 @@ def test_primed_call_on_a_hybrid_plan(ctx, oracle, mrs, small_inputs_take_the_sc
 
 
 @pytest.mark.parametrize("tile,log2n", [(4096, 20), (32768, 23)])
-def test_buckets_of_exactly_one_full_tile(ctx, oracle, mrs, small_inputs_take_the_schedule, monkeypatch, tile, log2n):
+def test_buckets_of_exactly_one_full_tile(ctx, oracle, mrs, small_inputs_take_the_schedule, aids, tile, log2n):
     """Every first-level bucket holds exactly one full tile of pass B (no partial tile anywhere, every
     tile the first and only one of its chain), in shuffled and in sorted input order."""
-    monkeypatch.setenv("MRS_HYBRID_MSD_BITS", "16")
+    aids(ctx.ATTR_TEST_HYBRID_LEADING_BITS, 16)
     n = 1 << log2n
     assert n // 256 == tile
     base = (np.arange(n, dtype=np.uint64) << np.uint64(32 - log2n)).astype(np.uint32)  # n distinct keys, evenly spaced

@@ -200,10 +200,10 @@ def test_sort_tile_shapes_triangle_payload(ctx, oracle, mrs, tile, algo_name):
 
 
 @pytest.mark.parametrize("key_words,payload_words,tile", [(1, 1, 0), (1, 1, 32768), (2, 4, 8192), (2, 1, 16384), (1, 0, 256)])
-def test_onesweep_wide_status_words(ctx, oracle, mrs, monkeypatch, key_words, payload_words, tile):
+def test_onesweep_wide_status_words(ctx, oracle, mrs, aids, key_words, payload_words, tile):
     """The 64-bit status words and 64-bit addressing that plans of 2^30 elements (or arrays above
     4 GiB) use, forced on an input the checker can sort."""
-    monkeypatch.setenv("MRS_FORCE_WIDE_STATUS", "1")
+    aids(ctx.ATTR_TEST_WIDE_STATUS, 1)
     n = 150001 if tile <= 8192 else 10 * tile + 9
     keys = make_keys(oracle, n, key_words, "random")
     vals = make_vals(oracle, n, payload_words)
@@ -216,11 +216,12 @@ def test_onesweep_wide_status_words(ctx, oracle, mrs, monkeypatch, key_words, pa
 
 
 @pytest.mark.parametrize("tile", [0, 256, 32768])
-def test_match_rank_fallback(oracle, mrs, monkeypatch, tile):
-    """A context created with MRS_RANK=match ranks by ballot matching (what a device that
-    fails the LDS-atomic order check would use); the default context ranks by LDS atomics."""
-    monkeypatch.setenv("MRS_RANK", "match")
+def test_match_rank_fallback(oracle, mrs, tile):
+    """A context whose rank mode is set to 0 ranks by ballot matching (what a device that fails
+    the LDS-atomic order check would use); the default context ranks by LDS atomics."""
     ctx2 = mrs.Context(0)
+    assert ctx2.rank_mode == "atomic"
+    ctx2.set_attribute(ctx2.ATTR_RANK_MODE, 0)
     assert ctx2.rank_mode == "match"
     n = 100003 if tile <= 8192 else 6 * tile + 1
     for key_words, payload_words in ((1, 1), (2, 4)):
@@ -237,14 +238,14 @@ def test_match_rank_fallback(oracle, mrs, monkeypatch, tile):
 
 @pytest.mark.parametrize("key_words,payload_words", SHAPES)
 @pytest.mark.parametrize("bits", [4, 8])
-def test_small_inputs_both_paths(ctx, oracle, mrs, monkeypatch, key_words, payload_words, bits):
+def test_small_inputs_both_paths(ctx, oracle, mrs, aids, key_words, payload_words, bits):
     """Inputs of at most 4096 elements are sorted by one workgroup in one launch; with
-    MRS_NO_SMALL_SORT they take the general multi-launch path.  Both must agree with the checker,
+    MRS_ATTR_TEST_NO_SMALL_SORT they take the general multi-launch path.  Both must agree with the checker,
     including the side the result lands on."""
     end = 32 * key_words
     for general in (False, True):
         if general:
-            monkeypatch.setenv("MRS_NO_SMALL_SORT", "1")
+            aids(ctx.ATTR_TEST_NO_SMALL_SORT, 1)
         for n in (1, 2, 63, 64, 65, 255, 256, 257, 1000, 3000, 4095, 4096):
             for dist in ("random", "all_equal"):
                 keys = make_keys(oracle, n, key_words, dist, seed=n)
@@ -687,7 +688,7 @@ LIVE_BYTES = [
 
 @pytest.mark.parametrize("payload_words", [1, 4])
 @pytest.mark.parametrize("lo_mask,hi_mask", LIVE_BYTES)
-def test_u64_passes_left_out(ctx, oracle, mrs, monkeypatch, lo_mask, hi_mask, payload_words):
+def test_u64_passes_left_out(ctx, oracle, mrs, aids, lo_mask, hi_mask, payload_words):
     """64-bit keys some of whose bytes are the same for every key: the device leaves those
     passes out (in pairs, so that the result still lands on the promised side) and the passes
     after them read from the other buffer pair.  Results must not change, with 8- and 4-bit
@@ -715,7 +716,7 @@ def test_u64_passes_left_out(ctx, oracle, mrs, monkeypatch, lo_mask, hi_mask, pa
     plan.sort_pairs(ka[: 2 * 100], va[: 100 * payload_words], torch.empty_like(ka), torch.empty_like(va), n=100)
     assert plan.passes_left_out() == 0  # the one-workgroup path keeps no record
     plan.close()
-    monkeypatch.setenv("MRS_NO_SMALL_SORT", "1")
+    aids(ctx.ATTR_TEST_NO_SMALL_SORT, 1)
     m = 777
     ko, vo, _ = gpu_sort(ctx, mrs, keys[: 2 * m], vals[: m * payload_words], m, 2, payload_words, 8, 0, 64, mrs.ALGO_ONESWEEP)
     rk, rv = oracle.stable_sort_pairs(keys[: 2 * m], vals[: m * payload_words], m, 2, payload_words, 0, 64)

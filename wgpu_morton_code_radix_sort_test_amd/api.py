@@ -67,6 +67,14 @@ class Context:
     ATTR_RANK_MODE = 1
     ATTR_DIE_AWARE_TICKETS = 2
     ATTR_NOALLOC_TIMEOUT = 3
+    ATTR_ROCTX_RANGES = 4
+    # aids for tests and A/B runs: a plan copies them from its context when it is created
+    ATTR_TEST_HYBRID_MIN_N = 5
+    ATTR_TEST_HYBRID_LEADING_BITS = 6
+    ATTR_TEST_HYBRID_FORCE_FALLBACK = 7
+    ATTR_TEST_NO_SMALL_SORT = 8
+    ATTR_TEST_NO_PASS_SKIP = 9
+    ATTR_TEST_WIDE_STATUS = 10
     NOALLOC_MAX_N = 1 << 26
 
     def attribute(self, which):
@@ -76,7 +84,7 @@ class Context:
         return int(value.value)
 
     def set_attribute(self, which, value):
-        """`mrs_context_set_attribute` (ATTR_DIE_AWARE_TICKETS only)."""
+        """`mrs_context_set_attribute`."""
         _lib.check(self.lib.mrs_context_set_attribute(self._h, int(which), int(value)))
 
     @property

@@ -4,6 +4,9 @@
 // (src/main.rs:594-665): for every digit it enqueues the histogram, prefix-sum
 // and scatter stages on one stream with ping-pong buffers
 // (src/main.rs:515-576), with no host synchronisation in between.
+#include <dlfcn.h>
+
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -30,6 +33,46 @@ int fail(int code, const char* fmt, ...)
 
 void clear_error() { g_last_error.clear(); }
 
+// ---- range markers for an external profiler (MRS_ATTR_ROCTX_RANGES) -------------------------
+// The reference names its compute passes for NSight (src/main.rs:583-662); roctx ranges are what
+// rocprofv3 shows in their place.  The roctx library is bound at run time, only when asked for.
+static std::atomic<bool> g_ranges_on{false};
+static int (*g_range_push)(const char*) = nullptr;
+static int (*g_range_pop)() = nullptr;
+
+static int bind_roctx()
+{
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (g_range_push && g_range_pop) return MRS_OK;
+    // rocprofv3 listens to the first; the second serves roctracer-based tools
+    const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+    for (const char* name : names) {
+        void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        auto push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        auto pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) {
+            g_range_push = push;
+            g_range_pop = pop;
+            return MRS_OK;
+        }
+    }
+    return fail(MRS_ERR_UNSUPPORTED, "no roctx library (librocprofiler-sdk-roctx.so, libroctx64.so) could be loaded");
+}
+
+ProfilerRange::ProfilerRange(const char* name) : pushed_(false)
+{
+    if (g_ranges_on.load(std::memory_order_relaxed) && g_range_push) {
+        (void)g_range_push(name);
+        pushed_ = true;
+    }
+}
+ProfilerRange::~ProfilerRange()
+{
+    if (pushed_ && g_range_pop) (void)g_range_pop();
+}
+
 // Zeroes device memory on a stream with a kernel of the library, not with the runtime's
 // asynchronous memset: the memset node that a stream capture makes of the latter was seen to
 // leave the memory untouched when the captured graph is replayed by the HIP runtime a PyTorch
@@ -52,6 +95,7 @@ __global__ __launch_bounds__(256) void clear_kernel(uint32_t* __restrict__ p, si
 int clear_async(void* p, size_t bytes, hipStream_t s)
 {
     if (bytes == 0) return MRS_OK;
+    const ProfilerRange range("Clear");
     if ((reinterpret_cast<uintptr_t>(p) & 3u) || (bytes & 3u))
         return fail(MRS_ERR_INVALID_ARGUMENT, "clear: address and size must be multiples of 4");
     const size_t words = bytes / 4;
@@ -115,11 +159,16 @@ bool config_supported(unsigned long long n, int key_words, int payload_bytes, in
         case 32768: c = {1024, 32}; break;
         default: return false;
     }
-    // tuning aid: MRS_TILE_SHAPE=threads,kpt overrides the default shape
-    if (const char* e = std::getenv("MRS_TILE_SHAPE")) {
-        int t = 0, k = 0;
-        if (std::sscanf(e, "%d,%d", &t, &k) == 2 && tile_items == 0) c = {t, k};
-    }
+    // tuning aid: MRS_TILE_SHAPE=threads,kpt overrides the default shape (read once per process)
+    static const KernelConfig forced = [] {
+        KernelConfig f{0, 0};
+        if (const char* e = std::getenv("MRS_TILE_SHAPE")) {
+            int t = 0, k = 0;
+            if (std::sscanf(e, "%d,%d", &t, &k) == 2) f = {t, k};
+        }
+        return f;
+    }();
+    if (forced.threads != 0 && tile_items == 0) c = forced;
     // what the kernel table holds (mrs_radix_dispatch.hpp): three shapes for every element type,
     // 1024 x 8 for 16-byte payloads, 1024 x 16 for payloads of at most 4 bytes, and the large
     // shapes for 32-bit keys with such payloads.  Anything else (the override above can name any
@@ -296,6 +345,7 @@ void forget_stream_activity(int device, hipStream_t s)
 
 static int launch_pass(const mrs_plan* p, int mode, const PassArgs& args, hipStream_t s)
 {
+    const ProfilerRange range("Indexing");  // src/main.rs:658
     PassArgs a = args;
     a.atomic_rank = p->ctx->lds_atomics_in_lane_order;
     if (p->desc.key_words == 1)
@@ -306,6 +356,7 @@ static int launch_pass(const mrs_plan* p, int mode, const PassArgs& args, hipStr
 static int launch_block_hist(const mrs_plan* p, uint32_t n, const void* keys, uint32_t num_tiles, uint32_t pass,
                              uint32_t* hist, hipStream_t s)
 {
+    const ProfilerRange range("Histogram calculation");  // src/main.rs:597
     if (p->desc.key_words == 1)
         return launch_block_histogram_u32(p->radix_bits, n, keys, p->tile_items, num_tiles, pass_shift(p, pass),
                                           pass_mask(p, pass), hist, s);
@@ -315,6 +366,7 @@ static int launch_block_hist(const mrs_plan* p, uint32_t n, const void* keys, ui
 
 static int launch_global_hist(const mrs_plan* p, const GlobalHistArgs& a, hipStream_t s)
 {
+    const ProfilerRange range("Histogram calculation");  // src/main.rs:597
     const uint64_t vec = p->desc.key_words == 1 ? 4 : 2;
     // Every workgroup ends with up to passes x radix atomic adds on the same global words, so
     // each gets at least 8 vectors per thread to amortise them (MRS_HIST_BLOCKS_PER_CU: tuning aid).
@@ -344,6 +396,7 @@ static int launch_global_hist(const mrs_plan* p, const GlobalHistArgs& a, hipStr
 // `n` != 0: the scan also fills the plan's pass_plan words (which passes need not run).
 static int launch_ghist_scan(const mrs_plan* p, uint32_t num_passes, uint32_t n, hipStream_t s, uint32_t keep_passes = 0)
 {
+    const ProfilerRange range("Small Prefix Sum");  // src/main.rs:625
     const unsigned threads = p->radix < 64 ? 64 : p->radix;
     uint32_t* pass_plan = n ? p->control->pass_plan : nullptr;
     if (p->radix_bits == 4)
@@ -457,13 +510,12 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
         return fail(MRS_ERR_UNSUPPORTED, "mrs_context_create: at most %d devices are supported", kMaxDevices);
     bool in_order = false, all_dies = false;
     void* scratch_ptr = nullptr;
-    const char* rank_env = std::getenv("MRS_RANK");
     {
         int prev = -1;
         MRS_HIP_TRY(hipGetDevice(&prev));
         MRS_HIP_TRY(hipSetDevice(device_id));
         int rc = MRS_OK;
-        if (!(rank_env && std::strcmp(rank_env, "match") == 0)) rc = probe_lds_atomic_order(&in_order);
+        rc = probe_lds_atomic_order(&in_order);
         if (rc == MRS_OK && prop.multiProcessorCount == 256) rc = probe_die_ids(&all_dies);
         // This device's copy of the static scratch array.  `scratch` itself is a host-side stand-in
         // for the symbol: only the address obtained here, with the device current, may be handed
@@ -492,6 +544,7 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount;
     c->lds_atomics_in_lane_order = in_order;
+    c->lds_atomic_probe_passed = in_order;
     c->workgroups_on_all_dies = all_dies;
     c->die_aware_tickets = all_dies;
     c->live_plans = 0;
@@ -518,6 +571,13 @@ extern "C" int mrs_context_get_attribute(const mrs_context* ctx, int attribute, 
             *value = flag ? 1 : 0;
             return MRS_OK;
         }
+        case MRS_ATTR_ROCTX_RANGES: *value = g_ranges_on.load() ? 1 : 0; return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_MIN_N: *value = static_cast<int64_t>(ctx->aids.hybrid_min_n); return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_LEADING_BITS: *value = ctx->aids.hybrid_leading_bits; return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_FORCE_FALLBACK: *value = ctx->aids.hybrid_force_fallback ? 1 : 0; return MRS_OK;
+        case MRS_ATTR_TEST_NO_SMALL_SORT: *value = ctx->aids.no_small_sort ? 1 : 0; return MRS_OK;
+        case MRS_ATTR_TEST_NO_PASS_SKIP: *value = ctx->aids.no_pass_skip ? 1 : 0; return MRS_OK;
+        case MRS_ATTR_TEST_WIDE_STATUS: *value = ctx->aids.wide_status ? 1 : 0; return MRS_OK;
         default: return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_get_attribute: unknown attribute %d", attribute);
     }
 }
@@ -526,12 +586,37 @@ extern "C" int mrs_context_set_attribute(mrs_context* ctx, int attribute, int64_
 {
     clear_error();
     if (!ctx) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_set_attribute: null context");
-    if (attribute != MRS_ATTR_DIE_AWARE_TICKETS)
-        return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_set_attribute: attribute %d cannot be set", attribute);
-    if (value != 0 && !ctx->workgroups_on_all_dies)
-        return fail(MRS_ERR_UNSUPPORTED, "mrs_context_set_attribute: workgroups were not seen on all 8 dies of this device");
-    ctx->die_aware_tickets = value != 0;
-    return MRS_OK;
+    switch (attribute) {
+        case MRS_ATTR_DIE_AWARE_TICKETS:
+            if (value != 0 && !ctx->workgroups_on_all_dies)
+                return fail(MRS_ERR_UNSUPPORTED, "mrs_context_set_attribute: workgroups were not seen on all 8 dies of this device");
+            ctx->die_aware_tickets = value != 0;
+            return MRS_OK;
+        case MRS_ATTR_RANK_MODE:
+            if (value != 0 && !ctx->lds_atomic_probe_passed)
+                return fail(MRS_ERR_UNSUPPORTED, "mrs_context_set_attribute: this device failed the lane-order check of returning LDS atomics");
+            ctx->lds_atomics_in_lane_order = value != 0;
+            return MRS_OK;
+        case MRS_ATTR_ROCTX_RANGES:
+            if (value != 0)
+                if (int rc = bind_roctx()) return rc;
+            g_ranges_on.store(value != 0);
+            return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_MIN_N:
+            if (value < 0) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_set_attribute: negative size");
+            ctx->aids.hybrid_min_n = static_cast<uint64_t>(value);
+            return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_LEADING_BITS:
+            if (value != 0 && (value < 14 || value > 16))
+                return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_set_attribute: leading bits must be 0 (default) or 14..16");
+            ctx->aids.hybrid_leading_bits = static_cast<uint32_t>(value);
+            return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_FORCE_FALLBACK: ctx->aids.hybrid_force_fallback = value != 0; return MRS_OK;
+        case MRS_ATTR_TEST_NO_SMALL_SORT: ctx->aids.no_small_sort = value != 0; return MRS_OK;
+        case MRS_ATTR_TEST_NO_PASS_SKIP: ctx->aids.no_pass_skip = value != 0; return MRS_OK;
+        case MRS_ATTR_TEST_WIDE_STATUS: ctx->aids.wide_status = value != 0; return MRS_OK;
+        default: return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_set_attribute: attribute %d cannot be set", attribute);
+    }
 }
 
 extern "C" int mrs_context_destroy(mrs_context* ctx)
@@ -566,9 +651,9 @@ static int fill_plan(mrs_plan* p, mrs_context* ctx, const mrs_plan_desc* d, cons
         resolved.algo = MRS_ALGO_ONESWEEP;
         // ranking by returning LDS atomics is all the gated kernels are built for; a device that
         // failed the lane-order check gets the plain chained-scan plan, and so does a plan too small
-        // ever to be offered the schedule (below 3 * 2^24 pairs; MRS_HYBRID_MIN_N, the test aid, lifts that)
-        hybrid = ctx->lds_atomics_in_lane_order && !std::getenv("MRS_FORCE_WIDE_STATUS") &&
-                 (d->n >= (3ull << 24) || std::getenv("MRS_HYBRID_MIN_N"));
+        // ever to be offered the schedule (below 3 * 2^24 pairs; MRS_ATTR_TEST_HYBRID_MIN_N lifts that)
+        hybrid = ctx->lds_atomics_in_lane_order && !ctx->aids.wide_status &&
+                 (d->n >= (3ull << 24) || ctx->aids.hybrid_min_n != 0);
         // the gated kernels exist for two tile shapes
         if (hybrid && resolved.tile_items == 0) resolved.tile_items = d->n >= (1ull << 20) ? 32768 : 4096;
         d = &resolved;
@@ -582,6 +667,7 @@ static int fill_plan(mrs_plan* p, mrs_context* ctx, const mrs_plan_desc* d, cons
         return fail(MRS_ERR_INVALID_ARGUMENT, "%s: bit range [%d, %d) invalid for a %d-bit key", who, d->begin_bit,
                     d->end_bit, key_bits);
     p->ctx = ctx;
+    p->aids = ctx->aids;
     p->desc = *d;
     p->hybrid = hybrid;
     p->radix_bits = d->digit_bits;
@@ -601,7 +687,7 @@ static int fill_plan(mrs_plan* p, mrs_context* ctx, const mrs_plan_desc* d, cons
             std::max<unsigned long long>(4ull * d->key_words, static_cast<unsigned long long>(d->payload_bytes));
         p->status_word_bytes = (d->n < (1ull << 30) && d->n * elem_bytes <= (1ull << 32)) ? 4 : 8;
         // test aid: the 64-bit instantiation on inputs small enough to check element by element
-        if (std::getenv("MRS_FORCE_WIDE_STATUS")) p->status_word_bytes = 8;
+        if (p->aids.wide_status) p->status_word_bytes = 8;
     }
     return MRS_OK;
 }
@@ -795,11 +881,11 @@ static int check_pair_buffers(const mrs_plan* plan, const void* ka, const void* 
 
 // Inputs below this size take the plan's ordinary passes: the local sort visits at least 2^14
 // sub-buckets whatever n is, 2^16 when more than 30 key bits are sorted, and each visit has a
-// latency of its own (measured break-even: 2^25.5 and 2^27 pairs).  MRS_HYBRID_MIN_N: test aid, to
+// latency of its own (measured break-even: 2^25.5 and 2^27 pairs).  aids.hybrid_min_n: test aid, to
 // run the schedule on inputs a checker can follow.
-static uint64_t hybrid_min_n(uint32_t width)
+static uint64_t hybrid_min_n(uint32_t width, const TestAids& aids)
 {
-    if (const char* e = std::getenv("MRS_HYBRID_MIN_N")) return std::strtoull(e, nullptr, 10);
+    if (aids.hybrid_min_n != 0) return aids.hybrid_min_n;
     return width <= 30 ? 1ull << 26 : (width == 31 ? 3ull << 25 : 1ull << 27);
 }
 
@@ -807,15 +893,12 @@ static uint64_t hybrid_min_n(uint32_t width)
 // evenly spread keys (two thirds of what a workgroup holds; fewer, fuller sub-buckets cost the
 // local sort fewer visits), at least 14, and at least so many that 16 bits or fewer are left for
 // the local sort.  A takes the larger half.
-static uint32_t hybrid_msd_bits(uint32_t width, uint32_t n)
+static uint32_t hybrid_msd_bits(uint32_t width, uint32_t n, const TestAids& aids)
 {
     uint32_t bits = 14;
     while (bits < 16 && (static_cast<uint64_t>(n) >> bits) > 5120) ++bits;
-    // MRS_HYBRID_MSD_BITS: test aid, the finer splits on inputs a checker can follow
-    if (const char* e = std::getenv("MRS_HYBRID_MSD_BITS")) {
-        const uint32_t forced = static_cast<uint32_t>(std::atoi(e));
-        if (forced >= 14 && forced <= 16) bits = forced;
-    }
+    // test aid: the finer splits on inputs a checker can follow
+    if (aids.hybrid_leading_bits >= 14 && aids.hybrid_leading_bits <= 16) bits = aids.hybrid_leading_bits;
     if (bits + 16 < width) bits = width - 16;
     return bits;
 }
@@ -852,19 +935,19 @@ static bool hybrid_window_split(uint32_t begin, uint32_t n, uint64_t lo, uint64_
 // Whether a sort of n pairs on key bits [begin, end) is offered the three-move schedule at all, and
 // with which split.  `window`: null, or two key values every key is known to lie between (the
 // sharded sort's local sorts: keys of one slice of the key space).
-static bool hybrid_choose_split(uint32_t begin, uint32_t end, uint64_t n, const uint64_t* window, HybridSplit* split)
+static bool hybrid_choose_split(uint32_t begin, uint32_t end, uint64_t n, const uint64_t* window, const TestAids& aids,
+                                HybridSplit* split)
 {
     const uint32_t n32 = static_cast<uint32_t>(n);
     if (window) {
-        const char* e = std::getenv("MRS_HYBRID_MIN_N");  // test aid, as in hybrid_min_n
-        const uint64_t min_n = e ? std::strtoull(e, nullptr, 10) : 3ull << 24;  // slices are never exact powers of two
+        const uint64_t min_n = aids.hybrid_min_n != 0 ? aids.hybrid_min_n : 3ull << 24;  // slices are never exact powers of two
         return n >= min_n && hybrid_window_split(begin, n32, window[0], window[1], split);
     }
     // above about 2^28.7 pairs even evenly spread keys leave sub-buckets a workgroup cannot hold
     // (6500 on average, 7680 at most): the device would refuse, so it is not asked
-    const uint32_t msd_bits = hybrid_msd_bits(end - begin, n32);
+    const uint32_t msd_bits = hybrid_msd_bits(end - begin, n32, aids);
     *split = HybridSplit{msd_bits, end - msd_bits, 0u, false};
-    return n >= hybrid_min_n(end - begin) && (n >> 16) <= 6500;
+    return n >= hybrid_min_n(end - begin, aids) && (n >> 16) <= 6500;
 }
 
 // The schedule of an MRS_ALGO_HYBRID plan (mrs_hybrid.hpp): both pass sequences are enqueued and the
@@ -887,8 +970,8 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
                                          split.base, hist_grid, plan->hyb_packed, plan->hyb_header, s))
         return rc;
     if (int rc = mark(plan, "msd_histogram", s)) return rc;
-    // MRS_HYBRID_FORCE_FALLBACK: test aid, the device takes the plan's ordinary passes whatever the keys are
-    const uint32_t force = std::getenv("MRS_HYBRID_FORCE_FALLBACK") ? kHybFallback : 0u;
+    // test aid: the device takes the plan's ordinary passes whatever the keys are
+    const uint32_t force = plan->aids.hybrid_force_fallback ? kHybFallback : 0u;
     if (int rc = hybrid_launch_scan(plan->hyb_packed, hist_grid, plan->hyb_tables, plan->hyb_header, n32,
                                     plan->tile_items, force, bits_b, s))
         return rc;
@@ -1010,8 +1093,8 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
     plan->hyb_last = false;
     plan->num_marks = 0;
     if (int rc = mark(plan, "start", s)) return rc;
-    // Small inputs: the whole sort in one launch of one workgroup (MRS_NO_SMALL_SORT=1: A/B aid).
-    if (plan->desc.algo == MRS_ALGO_ONESWEEP && n32 <= small_sort_capacity() && !std::getenv("MRS_NO_SMALL_SORT")) {
+    // Small inputs: the whole sort in one launch of one workgroup (aids.no_small_sort: A/B aid).
+    if (plan->desc.algo == MRS_ALGO_ONESWEEP && n32 <= small_sort_capacity() && !plan->aids.no_small_sort) {
         const bool in_b = (plan->num_passes % 2u) == 1u;
         SmallSortArgs a{};
         a.keys_in = keys_a;
@@ -1026,7 +1109,10 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
         a.end_bit = plan->desc.end_bit;
         a.num_passes = plan->num_passes;
         a.payload_bytes = plan->desc.payload_bytes;
-        if (int rc = launch_small_sort(plan->desc.key_words, plan->radix_bits, a, s)) return rc;
+        {
+            const ProfilerRange range("Indexing");
+            if (int rc = launch_small_sort(plan->desc.key_words, plan->radix_bits, a, s)) return rc;
+        }
         return mark(plan, "small_sort", s);
     }
     // (a primed call too: the three-move schedule takes its own 16-bit histogram, whatever the encoder
@@ -1034,13 +1120,12 @@ static int sort_pairs_impl(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_
     // at 2^28 points)
     if (plan->hybrid) {
         HybridSplit split{};
-        plan->hyb_last = hybrid_choose_split(plan->desc.begin_bit, plan->desc.end_bit, n, window, &split);
+        plan->hyb_last = hybrid_choose_split(plan->desc.begin_bit, plan->desc.end_bit, n, window, plan->aids, &split);
         if (plan->hyb_last) return sort_pairs_hybrid(plan, n32, keys_a, vals_a, keys_b, vals_b, s, indexed, split);
     }
     // 64-bit keys: passes whose digit is the same for every key are left out on the device
-    // (see global_histogram_scan_kernel; MRS_NO_PASS_SKIP=1: A/B aid)
-    static const bool no_pass_skip = std::getenv("MRS_NO_PASS_SKIP") != nullptr;
-    const bool skip_passes = plan->desc.algo == MRS_ALGO_ONESWEEP && plan->desc.key_words == 2 && !no_pass_skip;
+    // (see global_histogram_scan_kernel; aids.no_pass_skip: A/B aid)
+    const bool skip_passes = plan->desc.algo == MRS_ALGO_ONESWEEP && plan->desc.key_words == 2 && !plan->aids.no_pass_skip;
     plan->pass_plan_live = skip_passes;
     const TicketedCall ticketed(plan->ctx, s, plan->lineage, plan->desc.algo == MRS_ALGO_ONESWEEP);
     const uint32_t xcd_block = ticketed.block();
@@ -1121,7 +1206,7 @@ extern "C" int mrs_hybrid_split_for(uint64_t n, int32_t begin_bit, int32_t end_b
     if (begin_bit < 0 || end_bit > 32 || width < 25 || n == 0 || n >= (1ull << 30))
         return fail(MRS_ERR_UNSUPPORTED, "mrs_hybrid_split_for: MRS_ALGO_HYBRID sorts 25 to 32 bits of a 32-bit key, 0 < n < 2^30");
     HybridSplit split{};
-    out->offered = hybrid_choose_split(begin_bit, end_bit, n, window, &split) ? 1 : 0;
+    out->offered = hybrid_choose_split(begin_bit, end_bit, n, window, TestAids{}, &split) ? 1 : 0;
     if (!out->offered && window) return MRS_OK;  // no split exists for this window
     out->leading_bits = split.msd_bits;
     out->shift = split.shift;
@@ -1254,10 +1339,13 @@ extern "C" int mrs_morton_encode30_for_sort(mrs_plan* plan, const float* xyz_dev
     hipStream_t s = static_cast<hipStream_t>(stream);
     plan->primed_keys = nullptr;
     if (int rc = clear_async(plan->control->ghist, sizeof(plan->control->ghist), s)) return rc;
-    if (int rc = launch_encode30_with_histogram(plan->ctx->num_cus, xyz_dev, n, mn, mx, keys_dev, idx_dev,
-                                                plan->control->ghist, plan->desc.begin_bit, plan->desc.end_bit,
-                                                plan->radix_bits, plan->num_passes, s))
-        return rc;
+    {
+        const ProfilerRange range("Morton Coding");  // src/main.rs:583
+        if (int rc = launch_encode30_with_histogram(plan->ctx->num_cus, xyz_dev, n, mn, mx, keys_dev, idx_dev,
+                                                    plan->control->ghist, plan->desc.begin_bit, plan->desc.end_bit,
+                                                    plan->radix_bits, plan->num_passes, s))
+            return rc;
+    }
     plan->primed_keys = keys_dev;
     plan->primed_n = n;
     return MRS_OK;
@@ -1283,9 +1371,12 @@ extern "C" int mrs_sort_gather(mrs_plan* plan, uint64_t n, void* keys_a, void* k
     // the first pass makes the source indices up: no iota is written, none is read
     if (int rc = sort_pairs_impl(plan, n, keys_a, index_a, keys_b, index_b, s, &in_b, false, "mrs_sort_gather", true))
         return rc;
-    if (int rc = launch_gather(records_in, in_b ? index_b : index_a, records_out, static_cast<uint32_t>(n), record_bytes,
-                               plan->ctx->num_cus, s))
-        return rc;
+    {
+        const ProfilerRange range("Gather");
+        if (int rc = launch_gather(records_in, in_b ? index_b : index_a, records_out, static_cast<uint32_t>(n), record_bytes,
+                                   plan->ctx->num_cus, s))
+            return rc;
+    }
     return mark(plan, "gather", s);
 }
 

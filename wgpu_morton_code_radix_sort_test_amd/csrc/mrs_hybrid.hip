@@ -508,6 +508,7 @@ int hybrid_local_sort_grid(int num_cus)
 int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t bits, bool windowed, uint32_t window_base,
                             int grid, uint32_t* packed, HybridHeader* hdr, hipStream_t s)
 {
+    const ProfilerRange range("Histogram calculation");  // src/main.rs:597
     const uint32_t vectors = (reinterpret_cast<uintptr_t>(keys) & 15u) ? 0u : n / 4u;
     hipLaunchKernelGGL(hybrid_histogram_kernel, dim3(grid), dim3(1024), 0, s, keys, n, vectors, shift, bits, packed, hdr,
                        kHybLocalCap, window_base, windowed ? 1u : 0u);
@@ -519,6 +520,7 @@ int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, H
                        uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, hipStream_t s)
 {
     if (sub_bits < 6 || sub_bits > 8) return fail(MRS_ERR_UNSUPPORTED, "a bucket has 64 to 256 sub-buckets");
+    const ProfilerRange range("Small Prefix Sum");  // src/main.rs:625
     hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(kHybPackedWords / 64), dim3(256), 0, s, packed, grid, tables->counts);
     MRS_CHECK_LAUNCH("hybrid_reduce_kernel");
     hipLaunchKernelGGL(hybrid_scan_kernel, dim3(1), dim3(1024), 0, s, tables, hdr, n, tile_items, kHybLocalCap, force_mode, sub_bits);
@@ -544,6 +546,7 @@ int hybrid_launch_pass(bool segmented, bool persistent, bool windowed, int threa
                        const HybridHeader* hdr, const HybridTables* tables, uint32_t run_if_mode, uint32_t grid, hipStream_t s)
 {
     if (a.wide_status) return fail(MRS_ERR_UNSUPPORTED, "gated passes use 32-bit tile status words");
+    const ProfilerRange range("Indexing");  // src/main.rs:658
     if (grid == 0) grid = 1;
     if (persistent) {  // the plan's ordinary passes, or pass B of a sort that shares the device with nothing: plain digits
         if (windowed) return fail(MRS_ERR_UNSUPPORTED, "persistent gated passes take plain bit-field digits");
@@ -563,6 +566,7 @@ int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader*
     if (num_subs == 0 || num_subs > kHybSubs) return fail(MRS_ERR_UNSUPPORTED, "at most 65536 sub-buckets");
     if (bits1 == 0 || bits1 > 8 || bits2 == 0 || bits2 > 8)
         return fail(MRS_ERR_UNSUPPORTED, "the local sort takes two digits of 1 to 8 bits");
+    const ProfilerRange range("Local sort");
     hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreads, kHybLocalKpt>), dim3(grid), dim3(kHybLocalThreads), 0, s,
                        keys, vals, hdr, tables, shift, bits1, bits2, num_subs);
     MRS_CHECK_LAUNCH("hybrid_local_sort_kernel");

@@ -116,6 +116,29 @@ struct KernelConfig {
     int kpt;  // keys per thread
 };
 
+// What tests and A/B runs can ask of a plan (mrs_context_set_attribute, MRS_ATTR_TEST_*).
+struct TestAids {
+    uint64_t hybrid_min_n = 0;         // 0 = the library's thresholds
+    uint32_t hybrid_leading_bits = 0;  // 0 = chosen from n
+    bool hybrid_force_fallback = false;
+    bool no_small_sort = false;
+    bool no_pass_skip = false;
+    bool wide_status = false;
+};
+
+// A roctx range around the launches enqueued while the object lives, if ranges are switched on
+// (MRS_ATTR_ROCTX_RANGES); otherwise one relaxed load.
+class ProfilerRange {
+public:
+    explicit ProfilerRange(const char* name);
+    ~ProfilerRange();
+    ProfilerRange(const ProfilerRange&) = delete;
+    ProfilerRange& operator=(const ProfilerRange&) = delete;
+
+private:
+    bool pushed_;
+};
+
 }  // namespace mrs
 
 struct mrs_context {
@@ -125,6 +148,7 @@ struct mrs_context {
     // ascending lane order on this device (checked at creation): the digit passes may rank
     // with them.
     bool lds_atomics_in_lane_order;
+    bool lds_atomic_probe_passed;  // what the creation-time check found (the flag above can be cleared)
     // A large grid lands on all 8 dies in comparable shares (checked at creation): the digit
     // passes may hand consecutive tiles to workgroups of one die.
     bool workgroups_on_all_dies;
@@ -132,6 +156,8 @@ struct mrs_context {
     int live_plans;          // plans created on this context and not yet destroyed
     // Address, on this device, of the library's static scratch array (mrs_sort_pairs_noalloc).
     void* static_scratch;
+    // test and A/B aids (MRS_ATTR_TEST_*): copied into every plan at its creation
+    mrs::TestAids aids;
 };
 
 namespace mrs {
@@ -175,6 +201,7 @@ struct mrs_plan {
     // mrs_morton_encode30_for_sort left the digit histograms of these keys in `control`
     const void* primed_keys;
     uint64_t primed_n;
+    mrs::TestAids aids;  // the context's, as they were when the plan was created
     // optional per-launch timing (mrs_plan_set_timing): events recorded on the
     // caller's stream around every launch of the last mrs_sort_pairs call
     bool timing;

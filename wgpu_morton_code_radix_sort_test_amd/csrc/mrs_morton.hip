@@ -291,6 +291,7 @@ extern "C" int mrs_morton_encode_lut(mrs_context* ctx, const void* uniforms_dev,
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode_lut: uniforms and triangles must be 16-byte aligned");
     if ((reinterpret_cast<uintptr_t>(codes_dev) & 7u) || (reinterpret_cast<uintptr_t>(vertices_dev) & 3u))
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode_lut: misaligned codes or vertices");
+    const ProfilerRange range("Morton Coding");  // src/main.rs:583
     hipLaunchKernelGGL(morton_encode_lut_kernel, dim3(grid_for(n, ctx->num_cus)), dim3(kEncodeThreads), 0,
                        static_cast<hipStream_t>(stream), static_cast<const unsigned char*>(uniforms_dev),
                        static_cast<const unsigned char*>(vertices_dev), static_cast<unsigned long long>(num_vertices),
@@ -313,6 +314,7 @@ extern "C" int mrs_morton_encode30(mrs_context* ctx, const float* xyz_dev, uint6
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30: buffers must be 16-byte aligned");
     Bounds3 b;
     for (int c = 0; c < 3; ++c) { b.mn[c] = mn[c]; b.mx[c] = mx[c]; }
+    const ProfilerRange range("Morton Coding");  // src/main.rs:583
     hipLaunchKernelGGL(morton_encode30_kernel<false>, dim3(encode30_grid(n, ctx->num_cus)), dim3(kEncode30Threads), 0,
                        static_cast<hipStream_t>(stream), xyz_dev, static_cast<unsigned long long>(n), b, keys_dev,
                        idx_dev, EncodeHistogram{});

@@ -135,21 +135,31 @@ int launch_exclusive_scan(uint32_t* vals, uint64_t len, uint32_t* partials, hipS
     if (len == 0) return MRS_OK;
     const uint64_t chunks = scan_partials_len(len);
     if (chunks <= 4) {
+        const ProfilerRange range("Small Prefix Sum");  // src/main.rs:625
         hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(kScanThreads), 0, s, vals,
                            static_cast<unsigned long long>(len));
         MRS_CHECK_LAUNCH("scan_single_block_kernel");
         return MRS_OK;
     }
     if (chunks > 0x7FFFFFFFull) return fail(MRS_ERR_UNSUPPORTED, "histogram too long to scan");
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(static_cast<unsigned>(chunks)), dim3(kScanThreads), 0, s, vals,
-                       static_cast<unsigned long long>(len), partials);
-    MRS_CHECK_LAUNCH("scan_reduce_kernel");
-    hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(kScanThreads), 0, s, partials,
-                       static_cast<unsigned long long>(chunks));
-    MRS_CHECK_LAUNCH("scan_single_block_kernel");
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(static_cast<unsigned>(chunks)), dim3(kScanThreads), 0, s, vals,
-                       static_cast<unsigned long long>(len), partials);
-    MRS_CHECK_LAUNCH("scan_apply_kernel");
+    {
+        const ProfilerRange range("Large Prefix Sum part 1");  // src/main.rs:606
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(static_cast<unsigned>(chunks)), dim3(kScanThreads), 0, s, vals,
+                           static_cast<unsigned long long>(len), partials);
+        MRS_CHECK_LAUNCH("scan_reduce_kernel");
+    }
+    {
+        const ProfilerRange range("Small Prefix Sum");  // src/main.rs:625
+        hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(kScanThreads), 0, s, partials,
+                           static_cast<unsigned long long>(chunks));
+        MRS_CHECK_LAUNCH("scan_single_block_kernel");
+    }
+    {
+        const ProfilerRange range("Large Prefix Sum part 2");  // src/main.rs:635
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(static_cast<unsigned>(chunks)), dim3(kScanThreads), 0, s, vals,
+                           static_cast<unsigned long long>(len), partials);
+        MRS_CHECK_LAUNCH("scan_apply_kernel");
+    }
     return MRS_OK;
 }
 
