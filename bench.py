@@ -174,7 +174,56 @@ def cpu_baseline(sample_keys, sample_idx, whole):
     }, k1, i1
 
 
-def c4_leg(ctx, log2n=30, sorts=3):
+def rocprim_context(keys, vals, end_bit, want_k, want_v, sorts=3):
+    """Same-box context number (not a target, not part of the product): rocprim::radix_sort_pairs
+    on `keys`/`vals` (left untouched) over key bits [0, end_bit), timed with HIP events on torch's
+    current stream, its output compared with the library's (`want_k`, `want_v`).  None when
+    tools/librocprim_context.so has not been built."""
+    import ctypes
+
+    path = os.path.join(ROOT, "tools", "librocprim_context.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.rocprim_context_temp_bytes.restype = ctypes.c_size_t
+    lib.rocprim_context_temp_bytes.argtypes = [ctypes.c_size_t, ctypes.c_uint, ctypes.c_uint]
+    lib.rocprim_context_sort_pairs.restype = ctypes.c_int
+    lib.rocprim_context_sort_pairs.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p]
+    n = keys.numel()
+    temp_bytes = lib.rocprim_context_temp_bytes(n, 0, end_bit)
+    if temp_bytes == 0:
+        return {"error": "rocprim::radix_sort_pairs refused the size query"}
+    temp = torch.empty(temp_bytes, dtype=torch.uint8, device=keys.device)
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    times = []
+    for j in range(sorts + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = lib.rocprim_context_sort_pairs(temp.data_ptr(), temp_bytes, keys.data_ptr(), ko.data_ptr(), vals.data_ptr(),
+                                            vo.data_ptr(), n, 0, end_bit, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        if rc != 0:
+            return {"error": f"rocprim::radix_sort_pairs returned hipError {rc}"}
+        if j:  # the first sort warms up
+            times.append(e0.elapsed_time(e1))
+    ms = float(np.mean(times))
+    return {
+        "rocprim_gkeys_per_s": n / (ms * 1e-3) / 1e9,
+        "rocprim_ms_per_sort": round(ms, 4),
+        "pairs": n,
+        "key_bits": end_bit,
+        "temp_bytes": int(temp_bytes),
+        "verified": bool(torch.equal(ko, want_k) and torch.equal(vo, want_v)),
+        "what": f"rocprim::radix_sort_pairs (ROCm's device-wide radix sort, default config) on the same (key, index) pairs, "
+                f"input to output buffers, mean of {sorts} sorts after 1 warm-up, HIP events; `verified` = its keys and "
+                f"payload equal the library's output bit for bit",
+    }
+
+
+def c4_leg(ctx, log2n=30, sorts=3, context=False):
     """The 2^30-pair configuration (and, with log2n=31, the whole 2^31-pair job of the 8-GPU
     configuration on one GPU): 64-bit tile status words and offsets; HIP events of the library
     around every launch.  Returns None when the device is short of memory."""
@@ -201,8 +250,16 @@ def c4_leg(ctx, log2n=30, sorts=3):
     plan.check()
     ok = verify_sorted(keys, idx, pk)
     plan.close()
+    del kb, vb
+    rp = None
+    if context:
+        try:
+            rp = rocprim_context(pk, pi, 32, keys, idx, sorts=2)
+        except Exception as exc:  # a context number: the leg stands without it
+            rp = {"error": str(exc)}
     ms = float(np.mean(totals))
     return {
+        "rocprim_context": rp,
         "pairs": n,
         "ms_per_sort": round(ms, 4),
         "gkeys_per_s": n / (ms * 1e-3) / 1e9,
@@ -470,6 +527,20 @@ def main():
             extra[label] = round(float(np.median(times[1:])), 4)
         del xyz, ek, ei
 
+    context = None
+    if not distributed and rank == 0 and algo in (mrs.ALGO_ONESWEEP, mrs.ALGO_HYBRID):
+        # same-box context (never a target): the vendor's radix sort on one of the step inputs
+        try:
+            k_in, i_in = make_input(ctx, n, SEED + 777)
+            pk, pi = k_in.clone(), i_in.clone()
+            in_b = plan.sort_pairs(k_in, i_in, kb, vb)
+            plan.check()
+            want = (kb, vb) if in_b else (k_in, i_in)
+            context = rocprim_context(pk, pi, end_bit, want[0], want[1])
+            del k_in, i_in, pk, pi, want
+        except Exception as exc:
+            context = {"error": str(exc)}
+
     breakdown = {}
     if distributed:
         # the same roofline object at N > 1: digit passes of rank 0's local sort, HIP events on
@@ -518,7 +589,7 @@ def main():
             del pristine
         torch.cuda.empty_cache()
         try:
-            c4 = c4_leg(ctx)
+            c4 = c4_leg(ctx, context=True)
         except Exception as exc:  # an extra: the headline line stands without it
             c4 = {"error": str(exc)}
         # the whole 8-GPU job (2^31 pairs) on this one GPU: the one-GPU point of a curve over 2^31 keys
@@ -557,6 +628,7 @@ def main():
             "verified": verified,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "context": context,
         }
         line.update(extra)
         if c4 is not None:

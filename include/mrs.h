@@ -43,6 +43,8 @@ extern "C" {
 #define MRS_ERR_UNSUPPORTED (-3)
 #define MRS_ERR_OUT_OF_MEMORY (-4)
 #define MRS_ERR_DEVICE_TIMEOUT (-5)
+#define MRS_ERR_PEER_FAILED (-6) /* in-process transport: another rank of the group returned an error
+                                    from (or before) a collective; the group is dead from then on */
 
 /* pass algorithm */
 #define MRS_ALGO_THREE_KERNEL 0 /* histogram -> prefix sum -> scatter, as src/main.rs:594-665 */
@@ -299,8 +301,7 @@ int mrs_sort_pairs_primed(mrs_plan* plan, uint64_t n, void* keys_a, void* vals_a
                           void* vals_b, void* stream, int* result_in_b);
 
 /* mrs_sort_pairs for callers that cannot allocate (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference, whose every call
- * re-creates all of its buffers (src/main.rs:382-388).  Sorts n (u32 key, u32 payload) pairs on
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Sorts n (u32 key, u32 payload) pairs on
  * key bits [begin_bit, end_bit) with 8-bit digits and chained-scan passes, exactly as a plan
  * created for that n would, but takes no plan: the temporary memory (tile status words, digit
  * histograms, ticket counters) is a static array of the library's code object, about 8 MiB that
@@ -389,7 +390,11 @@ int mrs_comm_create_rccl(const void* unique_id, int32_t rank, int32_t world, mrs
 int mrs_comm_wrap_rccl(void* nccl_comm, int32_t rank, int32_t world, mrs_comm** out);
 /* `world` ranks inside one process, one host thread per rank: collectives are device copies behind
  * a host barrier.  Ranks may sit on different devices or share one (how the single-GPU tests run
- * the multi-rank path).  out[0 .. world) receives one handle per rank. */
+ * the multi-rank path).  out[0 .. world) receives one handle per rank.  A rank whose
+ * mrs_dist_sort_pairs fails (bad arguments, a HIP error, a count mismatch) marks the group: the
+ * ranks waiting in a collective, and every later collective of the group, return
+ * MRS_ERR_PEER_FAILED instead of waiting for a rank that will not come.  (Over RCCL a rank that
+ * fails alone leaves its peers in the collective, as in any RCCL program.) */
 int mrs_comm_create_local(int32_t world, mrs_comm** out);
 int mrs_comm_destroy(mrs_comm* comm);
 

@@ -85,16 +85,23 @@ def run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, tolerance, round
         except Exception as exc:  # noqa: BLE001 - reported by the main thread
             errors.append((r, exc))
 
-    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
-    for t in threads:
-        t.join()
+    join_all(threads)
     for c in comms:
         c.close()
     if errors:
         raise errors[0][1]
     return results, infos
+
+
+def join_all(threads, seconds=300):
+    """A rank that never comes back is a failure to report, not a run to wait out."""
+    for t in threads:
+        t.join(seconds)
+    stuck = [t.name for t in threads if t.is_alive()]
+    assert not stuck, f"rank threads still inside the library after {seconds} s: {stuck}"
 
 
 def check_against_oracle(oracle, results, host_keys, sizes, key_words, end_bit, tolerance):
@@ -258,9 +265,9 @@ def test_repeated_calls_and_shrinking_input(oracle, mrs):
         except Exception as exc:  # noqa: BLE001
             errors.append(exc)
 
-    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
     [t.start() for t in threads]
-    [t.join() for t in threads]
+    join_all(threads)
     [c.close() for c in comms]
     if errors:
         raise errors[0]
@@ -303,3 +310,46 @@ def test_dist_argument_errors(ctx, mrs):
     assert "n_local_max" in str(e.value)
     sorter.close()
     comm.close()
+
+
+@pytest.mark.parametrize("world,bad_rank", [(2, 0), (3, 1), (8, 7)])
+def test_a_failing_rank_releases_its_peers(mrs, world, bad_rank):
+    """One rank of an in-process group leaves mrs_dist_sort_pairs with an error (here: more pairs
+    than its handle was created for, found before the first collective).  The other ranks, which
+    are waiting for it at the host barrier of the first collective, must come back with
+    MRS_ERR_PEER_FAILED instead of waiting for ever, and so must every later call on the group."""
+    from wgpu_morton_code_radix_sort_test_amd import _lib
+    from wgpu_morton_code_radix_sort_test_amd.dist import Communicator, DistributedSorter
+
+    comms = Communicator.local(world)
+    n_max = 20000
+    codes, second = [None] * world, [None] * world
+
+    def body(r):
+        torch.cuda.set_device(0)
+        ctx = mrs.Context(0)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            n = n_max + 1 if r == bad_rank else n_max
+            keys = ctx.generate_u32(r, 1, n, stream=stream)
+            vals = torch.arange(n, dtype=torch.int32, device=ctx.device)
+            sorter = DistributedSorter(ctx, comms[r], n_max)
+            for slot, count in ((codes, n), (second, n_max)):
+                try:
+                    sorter.sort(keys, vals, n=count, stream=stream)
+                    slot[r] = 0
+                except mrs.MrsError as exc:
+                    slot[r] = exc.code
+            stream.synchronize()
+            sorter.close()
+
+    threads = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    join_all(threads, 120)
+    for c in comms:
+        c.close()
+    for r in range(world):
+        assert codes[r] == (_lib.MRS_ERR_INVALID_ARGUMENT if r == bad_rank else _lib.MRS_ERR_PEER_FAILED), (r, codes)
+        # the group stays dead: a correct call afterwards fails at once on every rank
+        assert second[r] == _lib.MRS_ERR_PEER_FAILED, (r, second)

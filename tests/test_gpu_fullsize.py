@@ -252,9 +252,10 @@ def test_sharded_sort_ranks_on_one_gpu_large(ctx, mrs, world, log2n, dist_name):
         except Exception as exc:  # noqa: BLE001
             errors.append(exc)
 
-    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
     [t.start() for t in threads]
-    [t.join() for t in threads]
+    [t.join(600) for t in threads]
+    assert not any(t.is_alive() for t in threads), "a rank thread is still inside the library after 600 s"
     [c.close() for c in comms]
     if errors:
         raise errors[0]
@@ -319,9 +320,10 @@ def test_first_sorts_of_in_process_ranks_never_starve(mrs):
             except Exception as exc:  # noqa: BLE001
                 errors.append(exc)
 
-        threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        threads = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
         [t.start() for t in threads]
-        [t.join() for t in threads]
+        [t.join(600) for t in threads]
+        assert not any(t.is_alive() for t in threads), "a rank thread is still inside the library after 600 s"
         [c.close() for c in comms]
         if errors:
             raise AssertionError(f"fresh set {rep}: {errors[0]}")

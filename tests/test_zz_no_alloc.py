@@ -42,7 +42,9 @@ def _noalloc_sort(ctx, keys, vals, n, begin, end):
     return (kb, vb, in_b) if in_b else (ka, va, in_b)
 
 
-@pytest.mark.parametrize("sizes", [((1 << 22) + 12345, 300007), (1 << 20, 4000), (70001, 1), (1 << 25, (1 << 20) + 1)])
+# the last pair fills the static scratch array completely: n = MRS_NOALLOC_MAX_N is 2048 tiles, all of its status words
+@pytest.mark.parametrize("sizes", [((1 << 22) + 12345, 300007), (1 << 20, 4000), (70001, 1), (1 << 25, (1 << 20) + 1),
+                                   (1 << 26, (1 << 26) - 32767)])
 def test_noalloc_matches_plan_sort_twice_in_a_row(ctx, oracle, mrs, sizes):
     for j, n in enumerate(sizes):
         begin, end = (0, 32) if j == 0 else (0, 30)

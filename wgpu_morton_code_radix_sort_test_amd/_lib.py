@@ -16,6 +16,7 @@ MRS_ERR_HIP = -2
 MRS_ERR_UNSUPPORTED = -3
 MRS_ERR_OUT_OF_MEMORY = -4
 MRS_ERR_DEVICE_TIMEOUT = -5
+MRS_ERR_PEER_FAILED = -6
 
 
 class MrsError(RuntimeError):

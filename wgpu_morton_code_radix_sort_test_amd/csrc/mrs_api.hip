@@ -792,9 +792,9 @@ extern "C" int mrs_plan_destroy(mrs_plan* plan)
     if (!plan) return MRS_OK;
     if (plan->timing) {
         const int cap = static_cast<int>(sizeof(plan->marks) / sizeof(plan->marks[0]));
-        for (int i = 0; i < cap; ++i) (void)hipEventDestroy(plan->marks[i]);
+        for (int i = 0; i < cap; ++i) MRS_TEARDOWN(hipEventDestroy(plan->marks[i]));
     }
-    if (plan->temp && plan->owns_temp) (void)hipFree(plan->temp);
+    if (plan->temp && plan->owns_temp) MRS_TEARDOWN(hipFree(plan->temp));
     if (plan->ctx) plan->ctx->live_plans--;
     delete plan;
     return MRS_OK;

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "mrs_internal.h"
@@ -46,6 +47,7 @@ static int load_rccl(const RcclApi** out)
     static std::mutex m;
     static RcclApi api;
     static bool tried = false;
+    static std::string load_error = "no candidate name could be opened";  // dlerror() is only valid right after the failing dlopen
     std::lock_guard<std::mutex> lock(m);
     if (!tried) {
         tried = true;
@@ -55,6 +57,7 @@ static int load_rccl(const RcclApi** out)
         for (const char* name : names) {
             api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (api.handle) break;
+            if (const char* e = dlerror()) load_error = e;
         }
         if (api.handle) {
 #define MRS_BIND(field, symbol) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, symbol))
@@ -72,7 +75,7 @@ static int load_rccl(const RcclApi** out)
 #undef MRS_BIND
         }
     }
-    if (!api.handle) return fail(MRS_ERR_UNSUPPORTED, "librccl.so could not be loaded: %s", dlerror());
+    if (!api.handle) return fail(MRS_ERR_UNSUPPORTED, "librccl.so could not be loaded: %s", load_error.c_str());
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather || !api.Send ||
         !api.Recv || !api.GroupStart || !api.GroupEnd || !api.GetErrorString)
         return fail(MRS_ERR_UNSUPPORTED, "librccl.so lacks a symbol this library binds");
@@ -112,6 +115,9 @@ struct mrs_comm {
                           const uint64_t* recv_off, const uint64_t* recv_cnt, hipStream_t s) = 0;
     // an error the transport noticed asynchronously since the last call
     virtual int check_async() { return MRS_OK; }
+    // this rank gives up on the call it is in (it returns an error to its caller): whatever the
+    // transport can do so that its peers do not wait for it
+    virtual void abandon() {}
 };
 
 namespace mrs {
@@ -184,20 +190,37 @@ struct LocalGroup {
         hipEvent_t ready = nullptr, done = nullptr;
     };
     std::vector<Post> post;
+    // Set, for good, by a rank that returns an error from a collective or gives up before one:
+    // the other ranks must not wait for it.  A dead group never blocks anybody again.
+    bool failed = false;
     explicit LocalGroup(int w) : world(w), handles_alive(w), post(w) {}
-    void barrier()
+    // false: a rank of the group has failed (the caller returns MRS_ERR_PEER_FAILED)
+    bool barrier()
     {
         std::unique_lock<std::mutex> lock(m);
+        if (failed) return false;
         const uint64_t gen = generation;
         if (++arrived == world) {
             arrived = 0;
             ++generation;
             cv.notify_all();
-        } else {
-            cv.wait(lock, [&] { return generation != gen; });
+            return true;
         }
+        cv.wait(lock, [&] { return generation != gen || failed; });
+        return !failed;
+    }
+    void fail_group()
+    {
+        std::lock_guard<std::mutex> lock(m);
+        failed = true;
+        cv.notify_all();
     }
 };
+
+static int peer_failed()
+{
+    return fail(MRS_ERR_PEER_FAILED, "local transport: another rank of the group failed; the group's collectives no longer run");
+}
 
 __global__ void sum_rows_kernel(const unsigned long long* __restrict__ rows, unsigned long long* __restrict__ out,
                                 uint32_t count, uint32_t num_rows)
@@ -228,19 +251,35 @@ struct LocalComm final : mrs_comm {
     int finish(hipStream_t s)
     {
         MRS_HIP_TRY(hipEventRecord(group->post[rank].done, s));
-        group->barrier();
+        if (!group->barrier()) return peer_failed();
         for (int p = 0; p < world; ++p)
             if (p != rank) MRS_HIP_TRY(hipStreamWaitEvent(s, group->post[p].done, 0));
         // the posts may be overwritten only after every rank has read them
-        group->barrier();
+        if (!group->barrier()) return peer_failed();
         return MRS_OK;
     }
+    void abandon() override { group->fail_group(); }
+    // A rank that fails inside a collective would leave the others at the next host barrier for
+    // ever: it marks the group first, and they return MRS_ERR_PEER_FAILED.
     int allreduce_allgather_u64(const uint64_t* send, uint64_t* reduced, uint64_t* gathered, size_t count,
                                 hipStream_t s) override
     {
+        const int rc = allreduce_allgather_body(send, reduced, gathered, count, s);
+        if (rc != MRS_OK) group->fail_group();
+        return rc;
+    }
+    int alltoallv(const ExchangeArrays& x, const uint64_t* send_off, const uint64_t* send_cnt, const uint64_t* recv_off,
+                  const uint64_t* recv_cnt, hipStream_t s) override
+    {
+        const int rc = alltoallv_body(x, send_off, send_cnt, recv_off, recv_cnt, s);
+        if (rc != MRS_OK) group->fail_group();
+        return rc;
+    }
+    int allreduce_allgather_body(const uint64_t* send, uint64_t* reduced, uint64_t* gathered, size_t count, hipStream_t s)
+    {
         if (int rc = prepare(s)) return rc;
         group->post[rank].send[0] = send;
-        group->barrier();
+        if (!group->barrier()) return peer_failed();
         for (int p = 0; p < world; ++p) {
             if (p != rank) MRS_HIP_TRY(hipStreamWaitEvent(s, group->post[p].ready, 0));
             MRS_HIP_TRY(hipMemcpyAsync(gathered + static_cast<size_t>(p) * count, group->post[p].send[0],
@@ -255,8 +294,8 @@ struct LocalComm final : mrs_comm {
         }
         return finish(s);
     }
-    int alltoallv(const ExchangeArrays& x, const uint64_t* send_off, const uint64_t* send_cnt, const uint64_t* recv_off,
-                  const uint64_t* recv_cnt, hipStream_t s) override
+    int alltoallv_body(const ExchangeArrays& x, const uint64_t* send_off, const uint64_t* send_cnt, const uint64_t* recv_off,
+                       const uint64_t* recv_cnt, hipStream_t s)
     {
         if (int rc = prepare(s)) return rc;
         LocalGroup::Post& me = group->post[rank];
@@ -264,7 +303,7 @@ struct LocalComm final : mrs_comm {
         me.send[1] = x.count > 1 ? x.send[1] : nullptr;
         me.send_off = send_off;
         me.send_cnt = send_cnt;
-        group->barrier();
+        if (!group->barrier()) return peer_failed();
         for (int p = 0; p < world; ++p) {
             const LocalGroup::Post& src = group->post[p];
             if (src.send_cnt[rank] != recv_cnt[p])
@@ -473,29 +512,43 @@ extern "C" int mrs_comm_destroy(mrs_comm* comm)
     return MRS_OK;
 }
 
-// Handles of several in-process ranks are destroyed by their threads at the same time; the runtime
-// calls below are made by one thread at a time (a process was seen to abort inside them otherwise).
+// Handles of several in-process ranks are destroyed by their host threads at the same time.  A
+// process was once seen to abort with two threads inside this function and none anywhere else in
+// the library.  Nothing of the library's own can dangle here: the per-device activity record
+// (mrs_api.hip) owns its event for the life of the process and keeps the stream of the last
+// die-aware call only as a value to compare, never to hand to the runtime; so what died were
+// runtime calls of two threads running side by side -- hipStreamDestroy of one handle's side
+// stream against the hipFree / hipHostFree of another (both walk the device's stream list), under
+// the HIP runtime a PyTorch process carries.  Until a run of the -DMRS_DESTROY_TRACE build names
+// the pair, the teardown of a handle is made by one thread at a time; creation and the sort calls
+// are not serialised.
+#ifndef MRS_DESTROY_TRACE
 static std::mutex g_destroy_mutex;
+#endif
 
 static void free_dist(mrs_dist* d)
 {
     if (!d) return;
+#ifndef MRS_DESTROY_TRACE
     std::lock_guard<std::mutex> lock(g_destroy_mutex);
+#endif
+    // not for the abort above: a later stream may be given the same handle value, and must not
+    // pass for the stream the last die-aware call ran on
     if (d->side && d->ctx) forget_stream_activity(d->ctx->device, d->side);
-    if (d->part_plan) (void)mrs_plan_destroy(d->part_plan);
+    if (d->part_plan) MRS_TEARDOWN(mrs_plan_destroy(d->part_plan));
     for (mrs_plan* p : d->sort_plan)
-        if (p) (void)mrs_plan_destroy(p);
-    if (d->side) (void)hipStreamDestroy(d->side);
+        if (p) MRS_TEARDOWN(mrs_plan_destroy(p));
+    if (d->side) MRS_TEARDOWN(hipStreamDestroy(d->side));
     for (hipEvent_t e : d->arrived)
-        if (e) (void)hipEventDestroy(e);
-    if (d->sorted_all) (void)hipEventDestroy(d->sorted_all);
+        if (e) MRS_TEARDOWN(hipEventDestroy(e));
+    if (d->sorted_all) MRS_TEARDOWN(hipEventDestroy(d->sorted_all));
     void* dev[] = {d->small, d->part_k, d->part_v, d->recv_k, d->recv_v, d->tmp_k, d->tmp_v};
     for (void* p : dev)
-        if (p) (void)hipFree(p);
-    if (d->h_hist) (void)hipHostFree(d->h_hist);
-    if (d->h_tables) (void)hipHostFree(d->h_tables);
+        if (p) MRS_TEARDOWN(hipFree(p));
+    if (d->h_hist) MRS_TEARDOWN(hipHostFree(d->h_hist));
+    if (d->h_tables) MRS_TEARDOWN(hipHostFree(d->h_tables));
     for (hipEvent_t e : d->marks)
-        if (e) (void)hipEventDestroy(e);
+        if (e) MRS_TEARDOWN(hipEventDestroy(e));
     delete d;
 }
 
@@ -678,11 +731,24 @@ extern "C" int mrs_dist_check(mrs_dist* dist, void* stream)
     return dist->comm->check_async();
 }
 
+static int dist_sort_pairs_impl(mrs_dist* dist, uint64_t n_local, const void* keys_in, const void* vals_in,
+                                void** keys_out, void** vals_out, uint64_t* n_out, void* stream);
+
 extern "C" int mrs_dist_sort_pairs(mrs_dist* dist, uint64_t n_local, const void* keys_in, const void* vals_in,
                                    void** keys_out, void** vals_out, uint64_t* n_out, void* stream)
 {
     clear_error();
     if (!dist || !keys_out || !n_out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_dist_sort_pairs: null argument");
+    const int rc = dist_sort_pairs_impl(dist, n_local, keys_in, vals_in, keys_out, vals_out, n_out, stream);
+    // a rank that leaves the call with an error tells its transport, so that peers that can be
+    // told (ranks of one process) do not wait for it in a collective
+    if (rc != MRS_OK) dist->comm->abandon();
+    return rc;
+}
+
+static int dist_sort_pairs_impl(mrs_dist* dist, uint64_t n_local, const void* keys_in, const void* vals_in,
+                                void** keys_out, void** vals_out, uint64_t* n_out, void* stream)
+{
     mrs_dist* d = dist;
     int cur = -1;
     MRS_HIP_TRY(hipGetDevice(&cur));

@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
+
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -35,6 +37,20 @@ int clear_async(void* p, size_t bytes, hipStream_t s);
             return ::mrs::fail(MRS_ERR_HIP, "launch of %s failed: %s", name,           \
                                hipGetErrorString(_e));                                 \
     } while (0)
+
+// Diagnostic builds (-DMRS_DESTROY_TRACE) print every runtime call of the teardown paths to stderr
+// with the calling thread, before and after, and do not serialise the teardown of sharded-sort
+// handles: a process that dies inside one of the calls leaves the names of the calls in flight.
+#ifdef MRS_DESTROY_TRACE
+#define MRS_TEARDOWN(expr)                                                                              \
+    do {                                                                                               \
+        std::fprintf(stderr, "[teardown %lx] > %s\n", (unsigned long)pthread_self(), #expr);           \
+        const int _rc = static_cast<int>(expr);                                                        \
+        std::fprintf(stderr, "[teardown %lx] < %s = %d\n", (unsigned long)pthread_self(), #expr, _rc); \
+    } while (0)
+#else
+#define MRS_TEARDOWN(expr) (void)(expr)
+#endif
 
 constexpr int kMaxPasses = 16;   // 64-bit keys with 4-bit digits
 constexpr int kMaxRadix = 256;
