@@ -54,12 +54,16 @@ extern "C" {
                                    src/main.rs:594 -- two chained-scan scatters by the top two
                                    digits (the second one bucket by bucket), then every one of
                                    the 65536 sub-buckets sorted inside a workgroup's LDS and
-                                   written back sequentially.  A 16-bit histogram taken first
-                                   lets the DEVICE fall back to the four MRS_ALGO_ONESWEEP
-                                   passes when a sub-bucket would not fit (clustered or equal
-                                   keys, n above about 2^28.8); the result, its side and its
+                                   written back sequentially.  An exact 16-bit histogram taken
+                                   first lets the DEVICE decide sub-bucket by sub-bucket: one
+                                   that does not fit a workgroup (equal keys, a cluster) is
+                                   sorted where it lies by two more chained-scan passes on the
+                                   remaining bits; only when more than 256 sub-buckets are
+                                   oversized, or they hold over a quarter of the pairs, does
+                                   the device fall back to the four MRS_ALGO_ONESWEEP passes
+                                   (also n above about 2^29.1).  The result, its side and its
                                    stability are those of MRS_ALGO_ONESWEEP either way.  Costs
-                                   about 34 MiB more temporary memory                           */
+                                   about 35 MiB more temporary memory                           */
 
 /* byte sizes of the reference buffer elements */
 #define MRS_MORTON_UNIFORMS_BYTES 51248 /* MortonCodeConstants, morton_code.wgsl:19-26 */
@@ -179,11 +183,10 @@ int mrs_plan_get_passes_left_out(mrs_plan* plan, void* stream, uint32_t* left_ou
 /* Synchronises `stream` and reports which pass schedule the most recent sort call on `plan`
  * ran: MRS_SCHEDULE_PASSES (every plan but MRS_ALGO_HYBRID ones, and inputs too small for the
  * other schedule), MRS_SCHEDULE_MSD (an MRS_ALGO_HYBRID plan whose keys the device found spread
- * well enough) or MRS_SCHEDULE_MSD_REFUSED (the device found a sub-bucket too large and ran the
- * ordinary passes).  *largest_sub_bucket (may be NULL) receives the size of the largest of the
- * sub-buckets the device counted, 0 when it counted none, 0xFFFFFFFF when it stopped counting
- * because one workgroup's share of a sub-bucket alone was too large.  For tests and harnesses; the
- * reference always runs its one schedule (src/main.rs:594-665). */
+ * well enough) or MRS_SCHEDULE_MSD_REFUSED (the device found too many or too full oversized
+ * sub-buckets and ran the ordinary passes).  *largest_sub_bucket (may be NULL) receives the size of
+ * the largest of the sub-buckets the device counted, 0 when it counted none.  For tests and
+ * harnesses; the reference always runs its one schedule (src/main.rs:594-665). */
 /* Host only, no GPU needed: how an MRS_ALGO_HYBRID plan for key bits [begin_bit, end_bit) would
  * go about a sort of n pairs.  `window`: NULL, or two key values every key lies between (what the
  * sharded sort knows of a rank's piece).  offered = 0: the plan's ordinary passes run on the
@@ -191,7 +194,7 @@ int mrs_plan_get_passes_left_out(mrs_plan* plan, void* stream, uint32_t* left_ou
  * the window leaves the local sort 16 bits or fewer).  Otherwise the two scatters take
  * leading_bits (14..16) bits from bit `shift` up -- of the key, or, windowed, of
  * (key >> shift) - base -- and the sort inside LDS the local_bits bits [begin_bit, shift).  The
- * device still refuses at run time if a sub-bucket exceeds 7680 pairs. */
+ * device still has the last word at run time (see mrs_plan_get_schedule, mrs_plan_get_oversized). */
 typedef struct mrs_hybrid_split {
     int32_t offered;
     int32_t windowed;
@@ -206,6 +209,14 @@ int mrs_hybrid_split_for(uint64_t n, int32_t begin_bit, int32_t end_bit, const u
 #define MRS_SCHEDULE_MSD 1
 #define MRS_SCHEDULE_MSD_REFUSED 2
 int mrs_plan_get_schedule(mrs_plan* plan, void* stream, int32_t* schedule, uint32_t* largest_sub_bucket);
+/* Synchronises `stream`.  For the most recent sort call on an MRS_ALGO_HYBRID plan that ran
+ * MRS_SCHEDULE_MSD: how many sub-buckets did not fit a workgroup of the local sort and were sorted
+ * where they lay by the two extra chained-scan passes (*sub_buckets, at most 256), how many pairs
+ * they held (*pairs, at most n / 4), and what a workgroup held in that call (*capacity: 10240 pairs
+ * when a pair could be staged in 6 bytes, its low 16 key bits and its payload, else 7680).  Zeros
+ * otherwise.  Any pointer may be NULL.  For tests and harnesses; no counterpart in the reference. */
+int mrs_plan_get_oversized(mrs_plan* plan, void* stream, uint32_t* sub_buckets, uint64_t* pairs,
+                           uint32_t* capacity);
 
 /* Measurement hook (the reference has no timers; its passes are named for an
  * external profiler, src/main.rs:583-662).  With timing enabled, mrs_sort_pairs
@@ -213,8 +224,10 @@ int mrs_plan_get_schedule(mrs_plan* plan, void* stream, int32_t* schedule, uint3
  * every launch.  mrs_plan_get_timings synchronises on the last event and
  * returns, for each launch of the most recent mrs_sort_pairs call, its
  * duration in milliseconds and a label of at most 31 characters
- * ("memset", "global_histogram", "histogram_scan", "onesweep_pass",
- * "block_histogram", "scan", "scatter").  labels_out holds cap * 32 bytes. */
+ * ("memset", "global_histogram", "histogram_scan", "onesweep_pass", "block_histogram", "scan",
+ * "scatter", "small_sort", "gather"; MRS_ALGO_HYBRID plans: "msd_histogram", "msd_scan",
+ * "fallback_histogram", "msd_pass_a", "msd_pass_b", "msd_local_sort", "msd_oversized_histogram",
+ * "msd_oversized_pass", "fallback_pass").  labels_out holds cap * 32 bytes. */
 int mrs_plan_set_timing(mrs_plan* plan, int enable);
 int mrs_plan_get_timings(mrs_plan* plan, int cap, float* ms_out, char* labels_out, int* count_out);
 

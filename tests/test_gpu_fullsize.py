@@ -70,14 +70,14 @@ def test_full_size_sort_properties(ctx, mrs, log2n, algo_name, bits):
 
 
 @pytest.mark.parametrize("log2n,end_bit,want", [(28, 30, "msd"), (28, 32, "refused"), (27, 30, "msd"), (26, 30, "msd"),
-                                                (26, 32, "passes"), (29, 30, "passes")])
+                                                (26, 32, "passes"), (29, 30, "msd")])
 def test_full_size_hybrid_plan_equals_four_passes(ctx, mrs, log2n, end_bit, want):
     """MRS_ALGO_HYBRID plans at the sizes they exist for, against the four-pass plan on the same
     input, pair for pair (a stable sort has one answer), plus the size-independent properties.
     30-bit codes declared as 32-bit keys leave three quarters of the leading buckets empty: the
     device refuses and the result is still that of the four passes; 2^26 pairs of 32-bit keys are
-    below the size the three-move schedule pays for, and 2^29 pairs above the size whose sub-buckets
-    fit a workgroup: the host does not enqueue it for either."""
+    below the size the three-move schedule pays for: the host does not enqueue it; 2^29 pairs leave
+    sub-buckets of 8192 pairs, which fit a workgroup that stages a pair in 6 bytes."""
     n = 1 << log2n
     xyz = ctx.generate_points(23, n)
     keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])

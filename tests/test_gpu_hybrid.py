@@ -27,7 +27,10 @@ def small_inputs_take_the_schedule(ctx, aids):
     aids(ctx.ATTR_TEST_HYBRID_MIN_N, 1)
 
 
-def _sort_with_plan(ctx, mrs, keys, vals, n, begin, end, capacity=None, tile_items=0, indexed=False):
+def _sort_with_plan(ctx, mrs, keys, vals, n, begin, end, capacity=None, tile_items=0, indexed=False, oversized=None, twice=False):
+    """One sort through an MRS_ALGO_HYBRID plan.  `oversized`: a list that receives what
+    mrs_plan_get_oversized reports; `twice`: the plan sorts the same input a second time (what the
+    first call left in the plan's tables must not leak into the second)."""
     plan = mrs.SortPlan(ctx, capacity or n, key_words=1, payload_bytes=4, digit_bits=8, begin_bit=begin, end_bit=end,
                         algo=mrs.ALGO_HYBRID, tile_items=tile_items)
     ka, va = to_dev(keys, ctx.device), to_dev(vals, ctx.device)
@@ -36,7 +39,15 @@ def _sort_with_plan(ctx, mrs, keys, vals, n, begin, end, capacity=None, tile_ite
     kb, vb = torch.full_like(ka, -1), torch.full_like(va, -1)
     in_b = plan.sort_pairs_indexed(ka, va, kb, vb, n=n) if indexed else plan.sort_pairs(ka, va, kb, vb, n=n)
     plan.check()
+    if twice:
+        ka.copy_(to_dev(keys, ctx.device))
+        if not indexed:
+            va.copy_(to_dev(vals, ctx.device))
+        in_b = plan.sort_pairs_indexed(ka, va, kb, vb, n=n) if indexed else plan.sort_pairs(ka, va, kb, vb, n=n)
+        plan.check()
     schedule, largest = plan.schedule()
+    if oversized is not None:
+        oversized.extend(plan.oversized())
     ko, vo = to_u32(kb if in_b else ka)[:n], to_u32(vb if in_b else va)[:n]
     plan.close()
     return ko, vo, in_b, schedule, largest
@@ -70,32 +81,147 @@ def test_every_distribution_either_schedule(ctx, oracle, mrs, small_inputs_take_
     ko, vo, in_b, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 0, 32)
     rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
     assert schedule in (mrs.SortPlan.SCHEDULE_MSD, mrs.SortPlan.SCHEDULE_MSD_REFUSED)
-    if dist in ("all_equal", "one_hot_digit", "few_distinct"):
-        assert schedule == mrs.SortPlan.SCHEDULE_MSD_REFUSED and largest > 7680, (dist, largest)
+    if dist == "all_equal":  # one sub-bucket holds everything: more than the quarter the extra passes may take
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD_REFUSED and largest == n, (dist, largest)
     assert np.array_equal(ko, rk) and np.array_equal(vo, rv), dist
     # the reference-structured pass loop of the checker agrees (src/main.rs:594-665 restated)
     lk, lv, _ = oracle.lsd_sort(keys, vals, n, 1, 1, 8, 0, 32, 256)
     assert np.array_equal(ko, lk) and np.array_equal(vo, lv)
 
 
-def test_sub_buckets_at_the_capacity(ctx, oracle, mrs, small_inputs_take_the_schedule):
-    """One sub-bucket of exactly 7680 pairs (the most a workgroup sorts) is taken; 7681 are refused."""
-    for size, want in ((7680, "msd"), (7681, "refused")):
-        n = size + 50000
-        rnd = oracle.gen_u32(3, 9, n)
-        keys = rnd.copy()
-        keys[:size] = (np.uint32(0xABCD) << np.uint32(16)) | (rnd[:size] & np.uint32(0xFFFF))
-        others = keys[size:]
-        others[(others >> np.uint32(16)) == np.uint32(0xABCD)] ^= np.uint32(0x80000000)
-        perm = np.random.RandomState(5).permutation(n)
-        keys = np.ascontiguousarray(keys[perm])
-        vals = make_vals(oracle, n, 1)
-        ko, vo, _, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 0, 32)
-        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
-        # a histogram workgroup that finds the 7681st key of a sub-bucket in its own share stops counting
-        assert largest == size or (want == "refused" and largest == 0xFFFFFFFF)
-        assert schedule == (mrs.SortPlan.SCHEDULE_MSD if want == "msd" else mrs.SortPlan.SCHEDULE_MSD_REFUSED)
+def _keys_with_sub_buckets(oracle, n, shift, sizes, low_kinds, begin=0, end=32, seed=3):
+    """n keys, evenly spread except that sub-bucket ids 0x2BCD, 0x2BCE, ... (the value of the bits
+    [shift, end)) hold exactly sizes[j] keys each, whose lower bits are random ("random"), all the
+    same ("equal") or drawn from five values ("few").  Shuffled."""
+    rnd = oracle.gen_u32(seed, 9, n)
+    keys = rnd.copy()
+    width = end - shift
+    ids = [(0x2BCD + j) & ((1 << width) - 1) for j in range(len(sizes))]
+    field = np.uint32(((1 << width) - 1) << shift)
+    low_mask = np.uint32((1 << shift) - 1)
+    # keep the evenly spread rest out of the chosen sub-buckets
+    taken = np.isin((keys & field) >> np.uint32(shift), np.array(ids, dtype=np.uint32))
+    keys[taken] ^= np.uint32(1 << (end - 1))
+    at = 0
+    for j, (size, kind) in enumerate(zip(sizes, low_kinds)):
+        low = rnd[at:at + size] & low_mask
+        if kind == "equal":
+            low[:] = np.uint32(0x1A5A5) & low_mask
+        elif kind == "few":
+            low = (np.array([1, 77, 300, 4097, 65535], dtype=np.uint32) & low_mask)[rnd[at:at + size] % 5]
+        keys[at:at + size] = (keys[at:at + size] & ~(field | low_mask)) | np.uint32(ids[j] << shift) | low
+        at += size
+    assert at <= n
+    perm = np.random.RandomState(5).permutation(n)
+    return np.ascontiguousarray(keys[perm])
+
+
+# (begin, end, leading bits, where the sub-bucket's own bits start, pairs a workgroup holds, keys above `end` differ)
+CAPACITY_CASES = [
+    (0, 32, 16, 16, 10240, False),  # 16 bits below the sub-bucket's: a pair is staged in 6 bytes
+    (0, 30, 16, 14, 10240, False),
+    (2, 32, 14, 18, 7680, False),   # 18 bits below: 8 bytes
+    (4, 31, 14, 17, 7680, True),    # 17 bits below: 8 bytes; the bit above the sorted range differs between keys and is carried along
+]
+
+
+def test_keys_that_differ_above_the_sorted_range(ctx, oracle, mrs, small_inputs_take_the_schedule, aids):
+    """Where a pair would be staged in 6 bytes (the sub-bucket's own bits start at bit 16 or below) the
+    key bits above the sorted range must be the same for every key; the device finds out while it
+    counts, and takes the ordinary passes if they are not: bits outside [begin, end) are carried
+    along untouched either way."""
+    aids(ctx.ATTR_TEST_HYBRID_LEADING_BITS, 14)
+    n = 200003
+    keys = make_keys(oracle, n, 1, "random", seed=77)
+    vals = make_vals(oracle, n, 1)
+    for high_vary in (True, False):
+        k = keys if high_vary else ((keys & np.uint32((1 << 25) - 1)) | np.uint32(0x5A000000))
+        ko, vo, in_b, schedule, _ = _sort_with_plan(ctx, mrs, k, vals, n, 0, 25)
+        rk, rv = oracle.stable_sort_pairs(k, vals, n, 1, 1, 0, 25)
+        assert schedule == (mrs.SortPlan.SCHEDULE_MSD_REFUSED if high_vary else mrs.SortPlan.SCHEDULE_MSD) and not in_b
         assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+@pytest.mark.parametrize("begin,end,leading,shift,cap,high_vary", CAPACITY_CASES)
+def test_sub_buckets_at_the_capacity(ctx, oracle, mrs, small_inputs_take_the_schedule, aids, begin, end, leading, shift, cap,
+                                     high_vary):
+    """A sub-bucket of exactly as many pairs as a workgroup holds is sorted inside LDS; one pair more
+    and it is sorted where it lies by the two extra passes (the schedule still runs)."""
+    aids(ctx.ATTR_TEST_HYBRID_LEADING_BITS, leading)
+    for size in (cap, cap + 1):
+        n = size + 60000
+        keys = _keys_with_sub_buckets(oracle, n, shift, [size], ["random"], begin, end, seed=size)
+        if not high_vary and end < 32:
+            keys &= np.uint32((1 << end) - 1)
+        vals = make_vals(oracle, n, 1)
+        info = []
+        ko, vo, in_b, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, begin, end, oversized=info)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, begin, end)
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD and not in_b
+        assert largest == size
+        assert info == ([0, 0, cap] if size == cap else [1, size, cap]), info
+        assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+@pytest.mark.parametrize("begin,end,leading,shift,cap,high_vary", CAPACITY_CASES)
+def test_mix_of_empty_normal_and_oversized_sub_buckets(ctx, oracle, mrs, small_inputs_take_the_schedule, aids, begin, end,
+                                                       leading, shift, cap, high_vary):
+    """Most sub-buckets empty or small, one exactly full, and four oversized ones whose lower bits are
+    random, all equal, few distinct values, random again: the oversized ones (under a quarter of the
+    pairs) are sorted by the two extra chained-scan passes, everything else inside LDS; twice on one
+    plan, as pairs and with indices made up by the first pass."""
+    aids(ctx.ATTR_TEST_HYBRID_LEADING_BITS, leading)
+    sizes = [cap, cap + 1, 40000, 23456, 3 * cap + 17]
+    kinds = ["random", "random", "equal", "few", "random"]
+    big = sum(sizes[1:])
+    n = 4 * big + cap + 12345
+    keys = _keys_with_sub_buckets(oracle, n, shift, sizes, kinds, begin, end, seed=leading)
+    if not high_vary and end < 32:
+        keys &= np.uint32((1 << end) - 1)
+    for indexed in (False, True):
+        vals = np.arange(n, dtype=np.uint32) if indexed else make_vals(oracle, n, 1)
+        info = []
+        ko, vo, in_b, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, begin, end, oversized=info, twice=True,
+                                                          indexed=indexed)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, begin, end)
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD and not in_b
+        assert largest == max(sizes) and info == [4, big, cap], (largest, info)
+        assert np.array_equal(ko, rk), "keys"
+        assert np.array_equal(vo, rv), "payload"
+
+
+def test_one_sub_bucket_with_most_of_the_pairs_is_refused(ctx, oracle, mrs, small_inputs_take_the_schedule):
+    """90 % of the pairs in one sub-bucket: the extra passes would move most pairs four times, so the
+    device takes the plan's ordinary passes; the result is the same stable sort."""
+    n = 500000
+    keys = _keys_with_sub_buckets(oracle, n, 16, [n * 9 // 10], ["random"])
+    vals = make_vals(oracle, n, 1)
+    info = []
+    ko, vo, in_b, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 0, 32, oversized=info)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+    assert schedule == mrs.SortPlan.SCHEDULE_MSD_REFUSED and not in_b
+    assert largest == n * 9 // 10 and info[:2] == [0, 0]
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+@pytest.mark.parametrize("count,want", [(256, "msd"), (257, "refused")])
+def test_at_most_256_oversized_sub_buckets(ctx, oracle, mrs, small_inputs_take_the_schedule, aids, count, want):
+    """The table of oversized sub-buckets has 256 entries: one more and the device takes the ordinary
+    passes (8-byte staging, so that the sub-buckets are as small as an oversized one can be)."""
+    aids(ctx.ATTR_TEST_HYBRID_LEADING_BITS, 14)
+    size = 7681
+    n = 4 * count * size + 100000
+    keys = _keys_with_sub_buckets(oracle, n, 18, [size] * count, ["random"] * count, 2, 32, seed=count)
+    vals = make_vals(oracle, n, 1)
+    info = []
+    ko, vo, in_b, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 2, 32, oversized=info)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 2, 32)
+    assert not in_b
+    if want == "msd":
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD and info == [count, count * size, 7680], info
+    else:
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD_REFUSED and info[:2] == [0, 0], info
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
 
 
 @pytest.mark.parametrize("msd_bits", [14, 15, 16])
@@ -109,8 +235,19 @@ def test_bit_ranges(ctx, oracle, mrs, small_inputs_take_the_schedule, aids, begi
     vals = make_vals(oracle, n, 1)
     ko, vo, in_b, schedule, _ = _sort_with_plan(ctx, mrs, keys, vals, n, begin, end)
     rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, begin, end)
-    assert schedule == mrs.SortPlan.SCHEDULE_MSD and not in_b
+    # the keys are random in all 32 bits: where the local sort would stage a pair in 6 bytes (the
+    # sub-bucket's own bits start at bit 16 or below) the device finds bits that differ above `end`
+    # and takes the ordinary passes
+    leading = max(msd_bits, end - begin - 16)
+    refused = end < 32 and end - leading <= 16
+    assert schedule == (mrs.SortPlan.SCHEDULE_MSD_REFUSED if refused else mrs.SortPlan.SCHEDULE_MSD) and not in_b
     assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+    if refused:  # the same keys without the bits above `end`: the schedule runs
+        keys = keys & np.uint32((1 << end) - 1)
+        ko, vo, in_b, schedule, _ = _sort_with_plan(ctx, mrs, keys, vals, n, begin, end)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, begin, end)
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD and not in_b
+        assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
 
 
 def test_device_refusal_can_be_forced(ctx, oracle, mrs, small_inputs_take_the_schedule, aids):
@@ -255,12 +392,14 @@ def test_fuzz(ctx, oracle, mrs, small_inputs_take_the_schedule):
         assert np.array_equal(vo, rv), what
 
 
-def test_two_streams_at_once(oracle, mrs, small_inputs_take_the_schedule):
+def test_two_streams_at_once(oracle, mrs):
     """Two hybrid plans of two contexts sorting on two streams at the same time, every attribute at
     its default: the second call finds the first one's die-aware passes in flight and deals its
     tiles from a single list (pass B included), so neither can starve the other."""
     n = 1 << 21
     ctxs = [mrs.Context(0), mrs.Context(0)]
+    for c in ctxs:  # inputs a checker can follow take the schedule; nothing else differs from the defaults
+        c.set_attribute(c.ATTR_TEST_HYBRID_MIN_N, 1)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     plans, bufs, host = [], [], []
     for j in range(2):

@@ -617,7 +617,7 @@ def test_single_ticket_list(oracle, mrs):
     ctx2.set_attribute(ctx2.ATTR_DIE_AWARE_TICKETS, 0)
     assert ctx2.attribute(ctx2.ATTR_DIE_AWARE_TICKETS) == 0
     with pytest.raises(mrs.MrsError):
-        ctx2.set_attribute(ctx2.ATTR_RANK_MODE, 0)
+        ctx2.set_attribute(ctx2.ATTR_COMPUTE_UNITS, 0)  # found on the device, not a setting
     n = 300007
     keys = make_keys(oracle, n, 1, "morton30")
     vals = make_vals(oracle, n, 1)

@@ -202,10 +202,13 @@ def test_hybrid_split_of_the_whole_key_space():
             assert 14 <= s.leading_bits <= 16 and s.shift == end - s.leading_bits and not s.windowed and s.base == 0
             assert s.local_bits == width - s.leading_bits and 9 <= s.local_bits <= 16
             min_n = (1 << 26) if width <= 30 else ((3 << 25) if width == 31 else (1 << 27))
-            assert bool(s.offered) == (min_n <= n and (n >> 16) <= 6500), (begin, end, n)
+            # a workgroup holds 10240 pairs when the sub-bucket's own bits start at bit 16 or below
+            # (a pair is then staged in 6 bytes of LDS), else 7680; evenly spread keys must leave a
+            # sixth of that free (the few sub-buckets that do not fit get two extra passes)
+            cap = 10240 if s.shift <= 16 else 7680
+            assert bool(s.offered) == (min_n <= n and (n >> s.leading_bits) <= cap * 5 // 6), (begin, end, n)
             if s.offered:
-                # evenly spread keys leave sub-buckets a workgroup holds (7680 pairs) with room to spare
-                assert n / (1 << s.leading_bits) <= 6501
+                assert n / (1 << s.leading_bits) <= cap * 5 // 6 + 1
                 # and no finer split than needed: the next coarser one would exceed about 5000 pairs
                 if s.leading_bits > max(14, width - 16):
                     assert n >> (s.leading_bits - 1) > 5120
@@ -242,7 +245,8 @@ def test_hybrid_split_of_a_window():
         assert s.base == lo >> s.shift
         subs = (hi >> s.shift) - s.base + 1
         assert subs <= 1 << s.leading_bits
-        assert n // subs <= 5120
+        # about 5000 pairs per sub-bucket, or with the finest split what a workgroup holds less a sixth
+        assert n // subs <= (5120 if s.leading_bits < 16 else (10240 if s.shift <= 16 else 7680) * 5 // 6)
     assert offered > 2000
     # a window so narrow that its keys cannot spread is not offered; nor is one too wide for n
     assert not _hybrid_split(lib, 1 << 27, 0, 32, (12345, 12345))[1].offered

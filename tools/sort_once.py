@@ -15,6 +15,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wgpu_morton_code_radix_sort_test_amd as mrs  # noqa: E402
 
 
+def surface_points(xyz, dist):
+    """Turns uniform points (n x 3, in place) into the named distribution."""
+    n = xyz.shape[0]
+    if dist == "cluster5":
+        m = n // 20
+        xyz[:m] = xyz[:m] * 0.02 + 0.4
+    elif dist == "shell":
+        d = xyz - 0.5
+        d /= d.norm(dim=1, keepdim=True).clamp_min(1e-6)
+        xyz.copy_(0.5 + 0.45 * d)
+    elif dist == "planes":
+        third = n // 3
+        xyz[:third, 0] = 0.3
+        xyz[third:2 * third, 1] = 0.55
+        xyz[2 * third:, 2] = 0.8
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=28)
@@ -26,13 +43,18 @@ def main():
     ap.add_argument("--key-words", type=int, default=1)
     ap.add_argument("--end-bit", type=int, default=0, help="one past the last key bit sorted on (0: the whole key)")
     ap.add_argument("--payload-bytes", type=int, default=4)
-    ap.add_argument("--dist", default="morton30", choices=["morton30", "random", "sorted", "equal"])
+    ap.add_argument("--dist", default="morton30", choices=["morton30", "random", "sorted", "equal", "cluster5", "shell", "planes"],
+                    help="morton30: codes of uniform points; cluster5: the same with 5 %% of the points in a small cube; "
+                         "shell / planes: codes of points on a sphere shell / on three axis-aligned planes")
+    ap.add_argument("--leading-bits", type=int, default=0, help="MRS_ATTR_TEST_HYBRID_LEADING_BITS (14..16; 0 = the library's choice)")
     ap.add_argument("--hi-mask", type=lambda v: int(v, 0), default=0xFFFFFFFF,
                     help="64-bit keys: mask applied to the high word (short codes have constant high bytes)")
     ap.add_argument("--gather", action="store_true",
                     help="sort (key, source index) and move each record of --payload-bytes once (mrs_sort_gather)")
     args = ap.parse_args()
     ctx = mrs.Context(0)
+    if args.leading_bits:
+        ctx.set_attribute(ctx.ATTR_TEST_HYBRID_LEADING_BITS, args.leading_bits)
     n = args.n or (1 << args.log2n)
     algo = {"onesweep": mrs.ALGO_ONESWEEP, "hybrid": mrs.ALGO_HYBRID}.get(args.algo, mrs.ALGO_THREE_KERNEL)
     plan = mrs.SortPlan(ctx, n, key_words=args.key_words, payload_bytes=4 if args.gather else args.payload_bytes,
@@ -44,9 +66,10 @@ def main():
     vb = torch.empty(max(1, n * pw), dtype=torch.int32, device=ctx.device)
     rows = []
     for it in range(args.iters):
-        if args.dist == "morton30":
+        if args.dist in ("morton30", "cluster5", "shell", "planes"):
             xyz = ctx.generate_points(7 + it, n)
             mn, mx = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+            surface_points(xyz, args.dist)
             keys, idx = ctx.morton_encode30(xyz, mn, mx)
             del xyz
             if kw == 2:
@@ -76,9 +99,15 @@ def main():
         rows.append(tm)
     last = rows[-1]
     total = sum(ms for lab, ms in last if not lab.startswith("whole call"))
-    print(json.dumps({"n": n, "tile_items": plan.info.tile_items, "threads": plan.info.threads,
+    extra = {}
+    if algo == mrs.ALGO_HYBRID:
+        schedule, largest = plan.schedule()
+        subs, pairs, cap = plan.oversized()
+        extra = {"schedule": {0: "passes", 1: "msd", 2: "msd refused by the device"}[schedule], "largest_sub_bucket": largest,
+                 "oversized_sub_buckets": subs, "oversized_pairs": pairs, "workgroup_capacity": cap}
+    print(json.dumps({"n": n, "dist": args.dist, "tile_items": plan.info.tile_items, "threads": plan.info.threads,
                       "launches": [(lab, round(ms, 4)) for lab, ms in last], "total_ms": round(total, 4),
-                      "gkeys_per_s": round(n / total / 1e6, 3)}))
+                      "gkeys_per_s": round(n / total / 1e6, 3), **extra}))
 
 
 if __name__ == "__main__":

@@ -379,3 +379,11 @@ class SortPlan:
         which, largest = ctypes.c_int32(0), ctypes.c_uint32(0)
         _lib.check(self.lib.mrs_plan_get_schedule(self._h, _stream(stream), ctypes.byref(which), ctypes.byref(largest)))
         return which.value, largest.value
+
+    def oversized(self, stream=None):
+        """`mrs_plan_get_oversized`: synchronises; (sub-buckets the last three-move sort found too large
+        for a workgroup and sorted with its two extra passes, pairs they held, pairs a workgroup held)."""
+        subs, pairs, cap = ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_uint32(0)
+        _lib.check(self.lib.mrs_plan_get_oversized(self._h, _stream(stream), ctypes.byref(subs), ctypes.byref(pairs),
+                                                   ctypes.byref(cap)))
+        return subs.value, pairs.value, cap.value

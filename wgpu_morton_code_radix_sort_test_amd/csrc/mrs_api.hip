@@ -692,28 +692,37 @@ static int fill_plan(mrs_plan* p, mrs_context* ctx, const mrs_plan_desc* d, cons
     return MRS_OK;
 }
 
+// Tiles the passes of the three-move schedule can have on an input of `num_tiles` tiles: pass B has
+// up to 256 more than the array (every bucket ends in a tile of its own); the two passes over the
+// oversized sub-buckets run only when those hold at most a quarter of the pairs, in at most 256
+// sub-buckets, each of which ends in a tile of its own.
+static uint64_t hybrid_tiles_b(uint64_t num_tiles) { return num_tiles + kHybBuckets; }
+static uint64_t hybrid_tiles_big(uint64_t num_tiles) { return num_tiles / 4 + kHybMaxBig + 1; }
+
 // Status-word bytes one call on `num_tiles` tiles uses (and clears).  The two schedules of a
 // hybrid plan never run in the same call, so they share the space: pass A takes the first pass
-// region, pass B, which has up to 256 tiles more than the array has (every bucket ends in a tile of
-// its own), what follows it.
+// region, pass B what follows it, the passes over oversized sub-buckets what follows that.
 static size_t status_bytes(const mrs_plan* p, uint64_t num_tiles)
 {
-    const size_t region = static_cast<size_t>(num_tiles) * p->radix * p->status_word_bytes;
-    size_t bytes = region * p->num_passes;
+    const size_t per_tile = static_cast<size_t>(p->radix) * p->status_word_bytes;
+    size_t bytes = num_tiles * per_tile * p->num_passes;
     if (p->hybrid) {
-        const size_t ab = region + static_cast<size_t>(num_tiles + kHybBuckets) * p->radix * p->status_word_bytes;
-        if (ab > bytes) bytes = ab;
+        const size_t msd = (num_tiles + hybrid_tiles_b(num_tiles) + 2 * hybrid_tiles_big(num_tiles)) * per_tile;
+        if (msd > bytes) bytes = msd;
     }
     return align_up(bytes, 256);
 }
 
+constexpr size_t kHybridClearedBytes = (sizeof(HybridCleared) + 255) / 256 * 256;
+
 // Device bytes a onesweep plan needs: [error flag, 256 B][control block][hybrid plans: header,
-// 256 B][status words][hybrid plans: tables, packed histograms].
+// spill counts, digit counts of oversized sub-buckets][status words][hybrid plans: tables, packed
+// histograms].
 static size_t onesweep_temp_bytes(const mrs_plan* p)
 {
     size_t bytes = 256 + kControlBytes + status_bytes(p, p->max_tiles);
     if (p->hybrid)
-        bytes += sizeof(HybridHeader) + hybrid_tables_bytes() +
+        bytes += kHybridClearedBytes + hybrid_tables_bytes() +
                  hybrid_packed_bytes(hybrid_histogram_grid(p->ctx->num_cus, p->desc.n));
     return bytes;
 }
@@ -728,8 +737,8 @@ static void bind_onesweep_memory(mrs_plan* p, void* temp)
     p->control = reinterpret_cast<OnesweepControl*>(p->zero_begin);
     p->status = p->zero_begin + kControlBytes;
     if (p->hybrid) {
-        p->hyb_header = reinterpret_cast<HybridHeader*>(p->status);
-        p->status += sizeof(HybridHeader);
+        p->hyb_cleared = reinterpret_cast<HybridCleared*>(p->status);
+        p->status += kHybridClearedBytes;
         char* after = p->status + status_bytes(p, p->max_tiles);
         p->hyb_tables = reinterpret_cast<HybridTables*>(after);
         p->hyb_packed = reinterpret_cast<uint32_t*>(after + hybrid_tables_bytes());
@@ -856,9 +865,28 @@ extern "C" int mrs_plan_get_schedule(mrs_plan* plan, void* stream, int32_t* sche
     MRS_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     if (!plan->hyb_last) return MRS_OK;
     HybridHeader h;
-    MRS_HIP_TRY(hipMemcpy(&h, plan->hyb_header, sizeof h, hipMemcpyDeviceToHost));
+    MRS_HIP_TRY(hipMemcpy(&h, &plan->hyb_cleared->hdr, sizeof h, hipMemcpyDeviceToHost));
     *schedule = h.mode == kHybRun ? MRS_SCHEDULE_MSD : MRS_SCHEDULE_MSD_REFUSED;
     if (largest_sub_bucket) *largest_sub_bucket = h.max_sub;
+    return MRS_OK;
+}
+
+extern "C" int mrs_plan_get_oversized(mrs_plan* plan, void* stream, uint32_t* sub_buckets, uint64_t* pairs,
+                                      uint32_t* capacity)
+{
+    clear_error();
+    if (!plan) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_get_oversized: null plan");
+    if (int rc = check_device(plan->ctx, "mrs_plan_get_oversized")) return rc;
+    if (sub_buckets) *sub_buckets = 0;
+    if (pairs) *pairs = 0;
+    if (capacity) *capacity = 0;
+    MRS_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (!plan->hyb_last) return MRS_OK;
+    HybridHeader h;
+    MRS_HIP_TRY(hipMemcpy(&h, &plan->hyb_cleared->hdr, sizeof h, hipMemcpyDeviceToHost));
+    if (sub_buckets) *sub_buckets = h.num_big;
+    if (pairs) *pairs = h.mode == kHybRun ? h.big_pairs : 0;
+    if (capacity) *capacity = plan->hyb_compact_ok ? kHybLocalCapCompact : kHybLocalCapFull;
     return MRS_OK;
 }
 
@@ -889,14 +917,22 @@ static uint64_t hybrid_min_n(uint32_t width, const TestAids& aids)
     return width <= 30 ? 1ull << 26 : (width == 31 ? 3ull << 25 : 1ull << 27);
 }
 
-// Key bits passes A and B take together: enough for sub-buckets of at most about 5000 pairs on
-// evenly spread keys (two thirds of what a workgroup holds; fewer, fuller sub-buckets cost the
-// local sort fewer visits), at least 14, and at least so many that 16 bits or fewer are left for
-// the local sort.  A takes the larger half.
-static uint32_t hybrid_msd_bits(uint32_t width, uint32_t n, const TestAids& aids)
+// What a workgroup of the local sort holds when the sub-bucket's own bits start at `shift`: with
+// 16 bits or fewer below them a pair is staged in 6 bytes (if the device finds no differing bits
+// above the sorted range either), else in 8.
+static uint32_t hybrid_local_cap(uint32_t shift) { return shift <= 16u ? kHybLocalCapCompact : kHybLocalCapFull; }
+
+// Key bits passes A and B take together: the coarsest split whose sub-buckets hold at most four
+// fifths of a workgroup's capacity on evenly spread keys (8192 of 10240 pairs, 5120 of 7680: every
+// visit of a sub-bucket costs the local sort about 4 microseconds whatever its size, so fewer,
+// fuller sub-buckets are faster -- 2^28 pairs: 0.95 ms with 2^15 sub-buckets, 1.19 ms with 2^16 --
+// and the fifth left free takes uneven keys), at least 14, and at least so many that 16 bits or
+// fewer are left for the local sort.  A takes the larger half.
+static uint32_t hybrid_msd_bits(uint32_t end, uint32_t width, uint32_t n, const TestAids& aids)
 {
     uint32_t bits = 14;
-    while (bits < 16 && (static_cast<uint64_t>(n) >> bits) > 5120) ++bits;
+    while (bits < 16 && (static_cast<uint64_t>(n) >> bits) > (hybrid_local_cap(end - bits) == kHybLocalCapCompact ? 8192u : 5120u))
+        ++bits;
     // test aid: the finer splits on inputs a checker can follow
     if (aids.hybrid_leading_bits >= 14 && aids.hybrid_leading_bits <= 16) bits = aids.hybrid_leading_bits;
     if (bits + 16 < width) bits = width - 16;
@@ -915,8 +951,9 @@ struct HybridSplit {
 // smallest shift that leaves at most that many sub-buckets over the window; the first of the three
 // whose sub-buckets would hold about 5000 pairs or fewer if the keys were spread evenly (a window
 // that is a little wider than a power of two needs the next shift, and with it twice the
-// sub-bucket size) and whose local sort gets at most 16 bits.  False when there is none (a window
-// too wide for this n, or so narrow that its keys cannot spread) or the window is empty.
+// sub-bucket size) and whose local sort gets at most 16 bits; failing that, the finest split if
+// evenly spread keys would still fit a workgroup with a sixth to spare.  False when there is none
+// (a window too wide for this n, or so narrow that its keys cannot spread) or the window is empty.
 static bool hybrid_window_split(uint32_t begin, uint32_t n, uint64_t lo, uint64_t hi, HybridSplit* out)
 {
     if (hi < lo || hi > 0xFFFFFFFFull) return false;
@@ -924,7 +961,8 @@ static bool hybrid_window_split(uint32_t begin, uint32_t n, uint64_t lo, uint64_
         uint32_t shift = begin + 2;  // the local sort takes two digits of at least one bit
         while (shift < 32 && ((hi >> shift) - (lo >> shift)) >= (1ull << bits)) ++shift;
         const uint64_t subs = (hi >> shift) - (lo >> shift) + 1;
-        if (shift - begin <= 16 && n / subs <= 5120) {
+        const uint64_t limit = bits < 16 ? (hybrid_local_cap(shift) == kHybLocalCapCompact ? 8192u : 5120u) : hybrid_local_cap(shift) * 5ull / 6;
+        if (shift - begin <= 16 && n / subs <= limit) {
             *out = HybridSplit{bits, shift, static_cast<uint32_t>(lo >> shift), true};
             return true;
         }
@@ -943,11 +981,13 @@ static bool hybrid_choose_split(uint32_t begin, uint32_t end, uint64_t n, const 
         const uint64_t min_n = aids.hybrid_min_n != 0 ? aids.hybrid_min_n : 3ull << 24;  // slices are never exact powers of two
         return n >= min_n && hybrid_window_split(begin, n32, window[0], window[1], split);
     }
-    // above about 2^28.7 pairs even evenly spread keys leave sub-buckets a workgroup cannot hold
-    // (6500 on average, 7680 at most): the device would refuse, so it is not asked
-    const uint32_t msd_bits = hybrid_msd_bits(end - begin, n32, aids);
+    // Evenly spread keys must leave sub-buckets a workgroup can hold with a sixth to spare (the few
+    // that do not fit are sorted by two extra passes, but not most of them): up to about 2^28.7
+    // pairs with 8-byte staging, 2^29.1 with 6-byte staging.  Beyond that the device would refuse,
+    // so it is not asked.
+    const uint32_t msd_bits = hybrid_msd_bits(end, end - begin, n32, aids);
     *split = HybridSplit{msd_bits, end - msd_bits, 0u, false};
-    return n >= hybrid_min_n(end - begin, aids) && (n >> 16) <= 6500;
+    return n >= hybrid_min_n(end - begin, aids) && (n >> msd_bits) <= hybrid_local_cap(split->shift) * 5ull / 6;
 }
 
 // The schedule of an MRS_ALGO_HYBRID plan (mrs_hybrid.hpp): both pass sequences are enqueued and the
@@ -958,7 +998,8 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     const uint32_t num_tiles = (n32 + plan->tile_items - 1) / plan->tile_items;
     const TicketedCall ticketed(plan->ctx, s, plan->lineage);
     const uint32_t xcd_block = ticketed.block();
-    const size_t region = static_cast<size_t>(num_tiles) * plan->radix * plan->status_word_bytes;
+    const size_t per_tile = static_cast<size_t>(plan->radix) * plan->status_word_bytes;
+    const size_t region = num_tiles * per_tile;
     const size_t zero = static_cast<size_t>(plan->status - plan->zero_begin) + status_bytes(plan, num_tiles);
     if (int rc = clear_async(plan->zero_begin, zero, s)) return rc;
     if (int rc = mark(plan, "memset", s)) return rc;
@@ -966,14 +1007,24 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     const int hist_grid = hybrid_histogram_grid(plan->ctx->num_cus, n32);
     const uint32_t msd_bits = split.msd_bits;
     const uint32_t bits_a = (msd_bits + 1) / 2, bits_b = msd_bits - bits_a;  // 7 or 8 each
+    // a pair of a sub-bucket can be staged as 16 key bits + payload if nothing below the
+    // sub-bucket's own bits is lost that way (the device still has a say: bits above end_bit)
+#ifdef MRS_NO_COMPACT  // A/B builds: 8-byte staging everywhere
+    const bool compact_ok = false;
+#else
+    const bool compact_ok = split.shift <= 16u;
+#endif
+    plan->hyb_compact_ok = compact_ok;
+    HybridCleared* hc = plan->hyb_cleared;
+    const HybridHeader* hdr = &hc->hdr;
     if (int rc = hybrid_launch_histogram(static_cast<const uint32_t*>(keys_a), n32, split.shift, msd_bits, split.windowed,
-                                         split.base, hist_grid, plan->hyb_packed, plan->hyb_header, s))
+                                         split.base, end_bit, hist_grid, plan->hyb_packed, hc, s))
         return rc;
     if (int rc = mark(plan, "msd_histogram", s)) return rc;
     // test aid: the device takes the plan's ordinary passes whatever the keys are
     const uint32_t force = plan->aids.hybrid_force_fallback ? kHybFallback : 0u;
-    if (int rc = hybrid_launch_scan(plan->hyb_packed, hist_grid, plan->hyb_tables, plan->hyb_header, n32,
-                                    plan->tile_items, force, bits_b, s))
+    if (int rc = hybrid_launch_scan(plan->hyb_packed, hist_grid, plan->hyb_tables, hc, n32, plan->tile_items, force, bits_b,
+                                    compact_ok, s))
         return rc;
     if (int rc = mark(plan, "msd_scan", s)) return rc;
     // the other schedule's digit histograms: counted only if the device chose it
@@ -984,17 +1035,46 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     h.end_bit = end_bit;
     h.num_passes = plan->num_passes;
     h.ghist = plan->control->ghist;
-    h.gate = &plan->hyb_header->mode;
+    h.gate = &hc->hdr.mode;
     h.gate_value = kHybFallback;
     if (int rc = launch_global_hist(plan, h, s)) return rc;
     if (int rc = mark(plan, "fallback_histogram", s)) return rc;
     if (int rc = launch_ghist_scan(plan, plan->num_passes, 0, s)) return rc;
     if (int rc = mark(plan, "histogram_scan", s)) return rc;
 
+    // Passes loop over tiles with one workgroup per compute unit where that costs nothing (same time
+    // per pass within 1 %): a launch with nothing to do is then 256 workgroups instead of 8448 (0.005
+    // against 0.10 ms), and one launch can serve both schedules.  Not inside a sharded sort, whose
+    // exchange kernels on the other stream would wait for the compute units until a pass ends: there
+    // passes A and B get a workgroup per tile and launches of their own.
+    const bool loop = !split.windowed && plan->lineage == nullptr;
+    const uint32_t cus = static_cast<uint32_t>(plan->ctx->num_cus);
+    const uint32_t persistent_grid = num_tiles < cus ? num_tiles : cus;
+    // the plan's ordinary passes, for inputs the device found unfit
+    PassArgs ordinary[4];
+    if (plan->num_passes != 4) return fail(MRS_ERR_UNSUPPORTED, "an MRS_ALGO_HYBRID plan has four ordinary passes");
+    for (uint32_t pass = 0; pass < 4; ++pass) {
+        const bool even = (pass % 2u) == 0u;
+        PassArgs& f = ordinary[pass];
+        f = PassArgs{};
+        f.keys_in = even ? keys_a : keys_b;
+        f.vals_in = even ? vals_a : vals_b;
+        f.keys_out = even ? keys_b : keys_a;
+        f.vals_out = even ? vals_b : vals_a;
+        f.n = n32;
+        f.num_tiles = num_tiles;
+        f.shift = pass_shift(plan, pass);
+        f.mask = pass_mask(plan, pass);
+        f.digit_base = plan->control->ghist + static_cast<size_t>(pass) * plan->radix;
+        f.status = plan->status + static_cast<size_t>(pass) * region;
+        f.tile_counter = plan->control->tile_counter[pass];
+        f.xcd_block = xcd_block;
+        f.error_flag = plan->error_flag;
+        f.index_payload = indexed && pass == 0;
+    }
     PassArgs a{};
     a.n = n32;
     a.num_tiles = num_tiles;
-    a.mask = 255u;
     a.wide_status = 0;
     a.xcd_block = xcd_block;
     a.error_flag = plan->error_flag;
@@ -1011,8 +1091,8 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     a.status = plan->status;
     a.tile_counter = plan->control->tile_counter[kMaxPasses - 2];
     a.index_payload = indexed;
-    if (int rc = hybrid_launch_pass(false, false, split.windowed, plan->threads, plan->kpt, a, plan->hyb_header,
-                                    plan->hyb_tables, kHybRun, num_tiles, s))
+    if (int rc = hybrid_launch_pass(&a, nullptr, loop ? &ordinary[0] : nullptr, loop, split.windowed, plan->threads, plan->kpt, hdr,
+                                    loop ? persistent_grid : num_tiles, s))
         return rc;
     if (int rc = mark(plan, "msd_pass_a", s)) return rc;
     // pass B: b -> a by the next digit, bucket by bucket
@@ -1028,43 +1108,56 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     a.tile_counter = plan->control->tile_counter[kMaxPasses - 1];
     a.index_payload = 0;
     a.xcd_block = xcd_block * 2;  // chains end with their bucket: larger blocks cost less here (0.834 -> 0.822 ms at 2^28)
-    // Pass B loops over tiles with one workgroup per compute unit where that costs nothing (same time per
-    // pass; pass A measured 1 % slower that way): a launch the device switched off is then 256 workgroups
-    // instead of 8448 (0.005 against 0.10 ms).  Not inside a sharded sort, whose exchange kernels on the
-    // other stream would wait for the compute units until the pass ends.
-    const bool loop_b = !split.windowed && plan->lineage == nullptr;
-    const uint32_t cus = static_cast<uint32_t>(plan->ctx->num_cus);
-    if (int rc = hybrid_launch_pass(true, loop_b, split.windowed, plan->threads, plan->kpt, a, plan->hyb_header,
-                                    plan->hyb_tables, kHybRun, loop_b ? (num_tiles < cus ? num_tiles : cus) : num_tiles + kHybBuckets, s))
+    const SegmentTable buckets{plan->hyb_tables->first_tile, plan->hyb_tables->bucket_start, plan->hyb_tables->bucket_start + 1,
+                               plan->hyb_tables->sub_start, a.mask + 1u, &hc->hdr.num_tiles_b};
+    if (int rc = hybrid_launch_pass(&a, &buckets, loop ? &ordinary[1] : nullptr, loop, split.windowed, plan->threads, plan->kpt, hdr,
+                                    loop ? persistent_grid : static_cast<uint32_t>(hybrid_tiles_b(num_tiles)), s))
         return rc;
     if (int rc = mark(plan, "msd_pass_b", s)) return rc;
-    // the remaining bits, inside LDS, in place
+    if (!loop) {
+        for (uint32_t pass = 0; pass < 2; ++pass) {
+            if (int rc = hybrid_launch_pass(nullptr, nullptr, &ordinary[pass], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
+                return rc;
+            if (int rc = mark(plan, "fallback_pass", s)) return rc;
+        }
+    }
+    // the remaining bits: two digits, least significant first
     const uint32_t low_bits = split.shift - begin_bit;  // 9..16, or 2..16 under a window
-    const uint32_t bits1 = (low_bits + 1) / 2;
-    if (int rc = hybrid_launch_local_sort(static_cast<uint32_t*>(keys_a), static_cast<uint32_t*>(vals_a), plan->hyb_header,
-                                          plan->hyb_tables, begin_bit, bits1, low_bits - bits1, 1u << msd_bits,
+    const uint32_t bits1 = (low_bits + 1) / 2, bits2 = low_bits - bits1;
+    // ... of the sub-buckets that fit a workgroup: inside LDS, in place
+    if (int rc = hybrid_launch_local_sort(static_cast<uint32_t*>(keys_a), static_cast<uint32_t*>(vals_a), hdr, plan->hyb_tables,
+                                          begin_bit, bits1, bits2, 1u << msd_bits, split.shift, compact_ok,
                                           hybrid_local_sort_grid(plan->ctx->num_cus), s))
         return rc;
     if (int rc = mark(plan, "msd_local_sort", s)) return rc;
-    // the plan's ordinary passes, for inputs the device found unfit: a few workgroups that return
-    // at once otherwise
-    const uint32_t persistent_grid = num_tiles < static_cast<uint32_t>(plan->ctx->num_cus) ? num_tiles : plan->ctx->num_cus;
-    for (uint32_t pass = 0; pass < plan->num_passes; ++pass) {
-        const bool even = (pass % 2u) == 0u;
-        a.keys_in = even ? keys_a : keys_b;
-        a.vals_in = even ? vals_a : vals_b;
-        a.keys_out = even ? keys_b : keys_a;
-        a.vals_out = even ? vals_b : vals_a;
-        a.shift = pass_shift(plan, pass);
-        a.mask = pass_mask(plan, pass);
-        a.digit_base = plan->control->ghist + static_cast<size_t>(pass) * plan->radix;
-        a.status = plan->status + static_cast<size_t>(pass) * region;
-        a.tile_counter = plan->control->tile_counter[pass];
-        a.index_payload = indexed && pass == 0;
-        if (int rc = hybrid_launch_pass(false, true, false, plan->threads, plan->kpt, a, plan->hyb_header, plan->hyb_tables,
-                                        kHybFallback, persistent_grid, s))
+    // ... of the oversized ones (the device's list; usually empty, and then these launches are a few
+    // hundred workgroups that return at once): their digit counts, then a -> b -> a inside each
+    // sub-bucket's own range, one chain per sub-bucket.  Plain bit-field digits also under a window.
+    // The same two launches are the last two ordinary passes of the other schedule.
+    if (int rc = hybrid_launch_big_histogram(static_cast<const uint32_t*>(keys_a), plan->hyb_tables, hc, plan->tile_items,
+                                             begin_bit, bits1, bits2, static_cast<int>(cus), s))
+        return rc;
+    if (int rc = mark(plan, "msd_oversized_histogram", s)) return rc;
+    const size_t big_region = hybrid_tiles_big(num_tiles) * per_tile;
+    for (uint32_t hh = 0; hh < 2; ++hh) {
+        a.keys_in = hh == 0 ? keys_a : keys_b;
+        a.vals_in = hh == 0 ? vals_a : vals_b;
+        a.keys_out = hh == 0 ? keys_b : keys_a;
+        a.vals_out = hh == 0 ? vals_b : vals_a;
+        a.shift = hh == 0 ? begin_bit : begin_bit + bits1;
+        a.mask = (1u << (hh == 0 ? bits1 : bits2)) - 1u;
+        a.window_base = 0;
+        a.window_low = 0;
+        a.digit_base = nullptr;
+        a.status = plan->status + region + hybrid_tiles_b(num_tiles) * per_tile + hh * big_region;
+        a.tile_counter = plan->control->tile_counter[kMaxPasses - 4 + hh];
+        a.index_payload = 0;
+        a.xcd_block = xcd_block;
+        const SegmentTable oversized{plan->hyb_tables->big_first_tile, plan->hyb_tables->big_start, plan->hyb_tables->big_end,
+                                     &hc->big_hist[0][hh][0], 512u, &hc->hdr.num_tiles_big};
+        if (int rc = hybrid_launch_pass(&a, &oversized, &ordinary[2 + hh], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
             return rc;
-        if (int rc = mark(plan, "fallback_pass", s)) return rc;
+        if (int rc = mark(plan, "msd_oversized_pass", s)) return rc;
     }
     return MRS_OK;
 }

@@ -709,12 +709,18 @@ extern "C" int mrs_dist_get_info(mrs_dist* dist, mrs_dist_info* info)
         if (int rc = mrs_plan_get_timings(dist->sort_plan[dist->chunks - 1], kMaxPasses * 4 + 8, ms, labels, &count)) return rc;
         float sum = 0.f;
         uint32_t passes = 0;
-        for (int i = 0; i < count; ++i)
-            if (std::strcmp(labels + 32 * i, "onesweep_pass") == 0 || std::strcmp(labels + 32 * i, "msd_pass_a") == 0 ||
-                std::strcmp(labels + 32 * i, "msd_pass_b") == 0) {
+        // the digit passes that ran: a launch of the schedule the device did not choose (or without
+        // oversized sub-buckets to move) returns at once, in a few microseconds
+        for (int i = 0; i < count; ++i) {
+            const char* lab = labels + 32 * i;
+            const bool pass_label = std::strcmp(lab, "onesweep_pass") == 0 || std::strcmp(lab, "msd_pass_a") == 0 ||
+                                    std::strcmp(lab, "msd_pass_b") == 0 || std::strcmp(lab, "fallback_pass") == 0 ||
+                                    std::strcmp(lab, "msd_oversized_pass") == 0;
+            if (pass_label && ms[i] > 0.03f) {
                 sum += ms[i];
                 ++passes;
             }
+        }
         info->last_sort_passes = passes;
         info->last_sort_pass_ms = passes ? sum / passes : 0.f;
     }

@@ -5,26 +5,30 @@
 
 namespace mrs {
 
-// ---- 16-bit histogram ---------------------------------------------------------------------
+// ---- exact 16-bit histogram -----------------------------------------------------------------
 // One LDS atomic per key into 65536 counters of 16 bits, two to a word (128 KiB: one workgroup
 // of 1024 threads per compute unit), 16-byte nontemporal loads, four in flight per thread.  A
-// workgroup writes its table to `packed`; hybrid_reduce_kernel adds the tables up.  A counter that
-// wraps (65536 keys of one workgroup in one sub-bucket) loses 65535 or 65536 from the sum of the
-// fields, never gains: a workgroup whose fields do not add up to the keys it counted raises
-// hdr->overflow, and the decision kernel then chooses the other schedule, which such an input
-// needs anyway.  The atomics return the old word: a lane that finds more than `cap` keys already
-// counted in its field knows that the sub-bucket is too large whatever the other workgroups hold,
-// raises the flag and lets the workgroup stop (equal or few distinct keys would otherwise queue
-// 64 lanes on one word for the whole input: 0.9 ms instead of 0.17 at 2^28).
+// workgroup writes its table to `packed`; hybrid_reduce_kernel adds the tables up.
+//
+// The counts are exact whatever the keys are.  A field never wraps: the one add that takes a
+// field from below 32768 to 32768 or more (exactly one add does, fields only grow) takes 32768
+// out again and puts it on the sub-bucket's 32-bit spill counter in global memory; until it has
+// done so the field can grow by what the workgroup has in flight, far below another 32768.  A
+// wave that finds a field already holding 512 of its workgroup's keys (evenly spread keys leave
+// about 16 at 2^28) counts differently from then on: the lanes of one instruction that hold the
+// first lane's sub-bucket are counted by ONE add of their number (equal or clustered keys would
+// otherwise queue 64 lanes on one word: 0.9 ms instead of 0.17 at 2^28 equal keys).  As a last
+// check a workgroup whose fields and spills do not add up to the keys it read raises
+// hdr->overflow, and the decision kernel then chooses the other schedule.
 __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                  uint32_t vectors, uint32_t shift, uint32_t bits,
-                                                                 uint32_t* __restrict__ packed, HybridHeader* hdr,
-                                                                 uint32_t cap, uint32_t window_base, uint32_t windowed)
+                                                                 uint32_t* __restrict__ packed, HybridCleared* hc,
+                                                                 uint32_t window_base, uint32_t windowed, uint32_t end_bit)
 {
     constexpr int THREADS = 1024, UNROLL = 4;
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kHybPackedWords];
     __shared__ int s_diff;
-    __shared__ volatile uint32_t s_stop;  // volatile: polled in the loops with no barrier in between
+    __shared__ uint32_t s_flags;  // bit 0: a key outside the window, bit 1: bits at or above end_bit differ
     const uint32_t tid = threadIdx.x;
     {
         uint4* z = reinterpret_cast<uint4*>(s_cnt);
@@ -32,31 +36,74 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
     }
     if (tid == 0) {
         s_diff = 0;
-        s_stop = 0;
+        s_flags = 0;
     }
     __syncthreads();
-    uint32_t mine = 0;
-    uint32_t most = 0;  // largest count this lane has seen in a field before its own increment
-    auto count = [&](uint32_t k) __attribute__((always_inline)) {
+    uint32_t mine = 0;     // keys this lane read
+    uint32_t spilled = 0;  // times this lane moved 32768 counts out of a field
+    uint32_t differ = 0;   // bits in which a key of this lane differs from the first key of the array
+    uint32_t outside = 0;  // a key of this lane lies outside the promised window
+    const uint32_t first_key = keys[0];
+    auto add_field = [&](uint32_t b, uint32_t amount) __attribute__((always_inline)) {
+        const uint32_t half = (b & 1u) * 16u;
+        const uint32_t old = atomicAdd(&s_cnt[b >> 1], amount << half);
+        const uint32_t before = (old >> half) & 0xFFFFu;
+        if (before < 0x8000u && before + amount >= 0x8000u) {
+            atomicSub(&s_cnt[b >> 1], 0x8000u << half);
+            atomicAdd(&hc->spill[b], 0x8000u);
+            ++spilled;
+        }
+    };
+    uint32_t most = 0;  // largest count this lane has found in a field
+    auto sub_bucket = [&](uint32_t k) __attribute__((always_inline)) {
+        differ |= k ^ first_key;
         uint32_t b = __builtin_amdgcn_ubfe(k, shift, bits);  // bits <= 16: counters beyond 2^bits stay zero
         if (windowed) {  // uniform
-            // sub-bucket = (key >> shift) - window_base; a key outside the window ends the count
-            // (the other schedule sorts any keys)
+            // sub-bucket = (key >> shift) - window_base; a key outside the window is counted somewhere
+            // and reported (the other schedule sorts any keys)
             b = (k >> shift) - window_base;
             if (b >> bits) {
-                most = cap;
+                outside = 1;
                 b = 0;
             }
         }
+        return b;
+    };
+    // evenly spread keys: one add per key and nothing else
+    auto count_plain = [&](uint32_t k) __attribute__((always_inline)) {
+        const uint32_t b = sub_bucket(k);
         const uint32_t half = (b & 1u) * 16u;
         const uint32_t old = atomicAdd(&s_cnt[b >> 1], 1u << half);
-        const uint32_t seen = (old >> half) & 0xFFFFu;
-        most = seen > most ? seen : most;
+        const uint32_t before = (old >> half) & 0xFFFFu;
+        most = before > most ? before : most;
+        if (before == 0x7FFFu) {
+            atomicSub(&s_cnt[b >> 1], 0x8000u << half);
+            atomicAdd(&hc->spill[b], 0x8000u);
+            ++spilled;
+        }
     };
-    // uniform for the wave; the other waves learn of it from LDS at their next step
-    auto too_many = [&]() {
-        if (__builtin_amdgcn_uicmp(most, cap, 35 /* >= */) != 0ull) s_stop = 1;
-        return s_stop != 0;
+    // keys that crowd on few sub-buckets: the lanes that hold the first lane's sub-bucket share one add
+    auto count_grouped = [&](uint32_t k) __attribute__((always_inline)) {
+        const uint32_t b = sub_bucket(k);
+        const uint32_t b0 = __builtin_amdgcn_readfirstlane(b);
+        const unsigned long long same = __builtin_amdgcn_uicmp(b, b0, 32 /* == */);  // among the active lanes
+        const uint32_t group = static_cast<uint32_t>(__popcll(same));
+        if (group >= 8u && b == b0) {
+            if (lanes_below(static_cast<uint32_t>(same), static_cast<uint32_t>(same >> 32)) == 0u) add_field(b0, group);
+        } else {
+            add_field(b, 1u);
+        }
+    };
+    // A wave counts the plain way until one of its lanes finds a field that already holds 512 keys
+    // of this workgroup (evenly spread keys leave a field about n / (65536 * workgroups) of them:
+    // 16 at 2^28), and the grouped way from then on.
+    bool crowded = false;  // uniform
+    auto count = [&](uint32_t k) __attribute__((always_inline)) {
+        if (crowded) count_grouped(k);
+        else count_plain(k);
+    };
+    auto look = [&]() __attribute__((always_inline)) {
+        if (!crowded && __builtin_amdgcn_uicmp(most, 512u, 35 /* >= */) != 0ull) crowded = true;
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4* __restrict__ vkeys = reinterpret_cast<const u32x4*>(keys);
@@ -67,16 +114,24 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
         u32x4 x[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) x[u] = __builtin_nontemporal_load(vkeys + v + u * stride);
+        if (crowded) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            count(x[u].x); count(x[u].y); count(x[u].z); count(x[u].w);
+            for (int u = 0; u < UNROLL; ++u) {
+                count_grouped(x[u].x); count_grouped(x[u].y); count_grouped(x[u].z); count_grouped(x[u].w);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                count_plain(x[u].x); count_plain(x[u].y); count_plain(x[u].z); count_plain(x[u].w);
+            }
+            look();
         }
         mine += 4 * UNROLL;
-        if (too_many()) break;
     }
-    for (; v < vectors && s_stop == 0; v += stride) {
+    for (; v < vectors; v += stride) {
         const u32x4 x = __builtin_nontemporal_load(vkeys + v);
         count(x.x); count(x.y); count(x.z); count(x.w);
+        look();
         mine += 4;
     }
     // what the vectors do not cover: everything if the array is not 16-byte aligned, else < 4 keys
@@ -84,12 +139,7 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
         count(keys[i]);
         mine += 1;
     }
-    if (most >= cap) s_stop = 1;  // seen in the last steps, which do not look
     __syncthreads();
-    if (s_stop != 0) {  // uniform: the counts are incomplete and nobody will read them
-        if (tid == 0) atomicOr(&hdr->overflow, 1u);
-        return;
-    }
     uint32_t fields = 0;
     {
         const uint4* c = reinterpret_cast<const uint4*>(s_cnt);
@@ -101,18 +151,29 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
                       (w.w & 0xFFFFu) + (w.w >> 16);
         }
     }
-    int diff = static_cast<int>(mine) - static_cast<int>(fields);
+    int diff = static_cast<int>(mine) - static_cast<int>(fields) - static_cast<int>(spilled * 0x8000u);
+    uint32_t flags = outside | ((end_bit < 32u && (differ >> end_bit) != 0u) ? 2u : 0u);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) diff += __shfl_down(diff, o);
-    if ((tid & 63u) == 0 && diff != 0) atomicAdd(&s_diff, diff);
+    for (int o = 32; o > 0; o >>= 1) {
+        diff += __shfl_down(diff, o);
+        flags |= __shfl_down(flags, o);
+    }
+    if ((tid & 63u) == 0) {
+        if (diff != 0) atomicAdd(&s_diff, diff);
+        if (flags != 0) atomicOr(&s_flags, flags);
+    }
     __syncthreads();
-    if (tid == 0 && s_diff != 0) atomicOr(&hdr->overflow, 1u);
+    if (tid == 0) {
+        if (s_diff != 0 || (s_flags & 1u)) atomicOr(&hc->hdr.overflow, 1u);
+        if (s_flags & 2u) atomicOr(&hc->hdr.high_vary, 1u);
+    }
 }
 
-// counts[i] = sum over the workgroups' tables of field i.  A workgroup owns 64 consecutive packed
-// words; its four waves each add up a quarter of the tables (256 bytes per table and wave), and
-// the quarters meet in LDS.
+// counts[i] = spill[i] + sum over the workgroups' tables of field i.  A workgroup owns 64
+// consecutive packed words; its four waves each add up a quarter of the tables (256 bytes per
+// table and wave), and the quarters meet in LDS.
 __global__ __launch_bounds__(256) void hybrid_reduce_kernel(const uint32_t* __restrict__ packed, int grid,
+                                                             const uint32_t* __restrict__ spill,
                                                              uint32_t* __restrict__ counts)
 {
     __shared__ uint32_t s_part[4][64][2];
@@ -144,22 +205,30 @@ __global__ __launch_bounds__(256) void hybrid_reduce_kernel(const uint32_t* __re
             lo += s_part[q][lane][0];
             hi += s_part[q][lane][1];
         }
-        reinterpret_cast<uint2*>(counts)[j] = make_uint2(lo, hi);
+        const uint2 sp = reinterpret_cast<const uint2*>(spill)[j];
+        reinterpret_cast<uint2*>(counts)[j] = make_uint2(lo + sp.x, hi + sp.y);
     }
 }
 
 // One workgroup: exclusive scan of the 65536 counts (thread t owns entries 64t .. 64t+63; a bucket
 // has 2^sub_bits >= 64 sub-buckets, so it starts with a thread), bucket starts, the tile table of
-// pass B and the decision.  Buckets and sub-buckets the split does not use are empty and start at n.
-__global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, HybridHeader* hdr, uint32_t n,
-                                                            uint32_t tile_items, uint32_t cap, uint32_t force_mode,
-                                                            uint32_t sub_bits)
+// pass B, the list of oversized sub-buckets with their tile table, and the decision.  Buckets and
+// sub-buckets the split does not use are empty and start at n.
+__global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, HybridCleared* hc, uint32_t n,
+                                                            uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits,
+                                                            uint32_t compact_ok)
 {
     __shared__ uint32_t s_wsum[16];
+    __shared__ uint32_t s_bigw[16];
     __shared__ uint32_t s_bstart[kHybBuckets + 1];
     __shared__ uint32_t s_tsum[4];
-    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_bigtsum[4];
+    __shared__ uint32_t s_bigcnt[kHybMaxBig];
+    __shared__ uint32_t s_max, s_bigpairs;
+    HybridHeader* hdr = &hc->hdr;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // what a workgroup of the local sort can hold
+    const uint32_t cap = compact_ok != 0u ? kHybLocalCapCompact : kHybLocalCapFull;
     uint32_t c[64];
     {
         const uint4* c4 = reinterpret_cast<const uint4*>(tb->counts) + tid * 16;
@@ -169,30 +238,52 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
             c[4 * q] = x.x; c[4 * q + 1] = x.y; c[4 * q + 2] = x.z; c[4 * q + 3] = x.w;
         }
     }
-    uint32_t sum = 0, mx = 0;
+    uint32_t sum = 0, mx = 0, nbig = 0, bigp = 0;
 #pragma unroll
     for (int q = 0; q < 64; ++q) {
         sum += c[q];
         mx = c[q] > mx ? c[q] : mx;
+        nbig += c[q] > cap ? 1u : 0u;
+        bigp += c[q] > cap ? c[q] : 0u;
     }
-    uint32_t incl = sum;
+    uint32_t incl = sum, bincl = nbig;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t y = __shfl_up(incl, o);
-        if (lane >= static_cast<uint32_t>(o)) incl += y;
+        const uint32_t z = __shfl_up(bincl, o);
+        if (lane >= static_cast<uint32_t>(o)) {
+            incl += y;
+            bincl += z;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const uint32_t y = __shfl_down(mx, o);
         mx = y > mx ? y : mx;
+        bigp += __shfl_down(bigp, o);
     }
-    if (lane == 63) s_wsum[wave] = incl;
-    if (tid == 0) s_max = 0;
+    if (lane == 63) {
+        s_wsum[wave] = incl;
+        s_bigw[wave] = bincl;
+    }
+    if (tid == 0) {
+        s_max = 0;
+        s_bigpairs = 0;
+    }
+    if (tid < kHybMaxBig) s_bigcnt[tid] = 0;
     __syncthreads();
-    if (lane == 0) atomicMax(&s_max, mx);
-    uint32_t run = incl - sum;
-    for (uint32_t w = 0; w < 16; ++w)
-        if (w < wave) run += s_wsum[w];
+    if (lane == 0) {
+        atomicMax(&s_max, mx);
+        if (bigp) atomicAdd(&s_bigpairs, bigp);
+    }
+    uint32_t run = incl - sum, bigoff = bincl - nbig, total_big = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < wave) {
+            run += s_wsum[w];
+            bigoff += s_bigw[w];
+        }
+        total_big += s_bigw[w];
+    }
     // thread t starts bucket t >> (sub_bits - 6) if it starts one; the threads past the last bucket
     // the split uses hold zeros, so the unused buckets start at n
     const uint32_t tpb = sub_bits - 6u;  // log2(threads per bucket)
@@ -211,70 +302,203 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
         }
         if (tid == 1023) tb->sub_start[kHybSubs] = run;
     }
+    // the oversized sub-buckets, in key order (rare: a second walk over the thread's counts)
+    if (nbig != 0u) {
+        uint32_t at = run - sum;
+#pragma unroll 1
+        for (int q = 0; q < 64; ++q) {
+            if (c[q] > cap) {
+                if (bigoff < kHybMaxBig) {
+                    tb->big_start[bigoff] = at;
+                    tb->big_end[bigoff] = at + c[q];
+                    s_bigcnt[bigoff] = c[q];
+                }
+                ++bigoff;
+            }
+            at += c[q];
+        }
+    }
     __syncthreads();
-    uint32_t tiles = 0, tincl = 0;
+    uint32_t tiles = 0, tincl = 0, bigtiles = 0, bigtincl = 0;
     if (tid < kHybBuckets) {
         const uint32_t bs = s_bstart[tid];
         const uint32_t cnt = s_bstart[tid + 1] - bs;
         tiles = (cnt + tile_items - 1) / tile_items;
         tb->bucket_start[tid] = bs;
         tincl = tiles;
+        bigtiles = (s_bigcnt[tid] + tile_items - 1) / tile_items;  // kHybMaxBig == kHybBuckets: one thread per entry of either table
+        bigtincl = bigtiles;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t y = __shfl_up(tincl, o);
-            if (lane >= static_cast<uint32_t>(o)) tincl += y;
+            const uint32_t z = __shfl_up(bigtincl, o);
+            if (lane >= static_cast<uint32_t>(o)) {
+                tincl += y;
+                bigtincl += z;
+            }
         }
-        if (lane == 63) s_tsum[wave] = tincl;
+        if (lane == 63) {
+            s_tsum[wave] = tincl;
+            s_bigtsum[wave] = bigtincl;
+        }
     }
     if (tid == kHybBuckets) tb->bucket_start[kHybBuckets] = s_bstart[kHybBuckets];
     __syncthreads();
     if (tid < kHybBuckets) {
-        uint32_t off = tincl - tiles;
+        uint32_t off = tincl - tiles, bigoff_t = bigtincl - bigtiles;
         for (uint32_t w = 0; w < 4; ++w)
-            if (w < wave) off += s_tsum[w];
+            if (w < wave) {
+                off += s_tsum[w];
+                bigoff_t += s_bigtsum[w];
+            }
         tb->first_tile[tid] = off;
+        tb->big_first_tile[tid] = bigoff_t;  // entries past the last oversized sub-bucket: the total
         if (tid == kHybBuckets - 1) {
             const uint32_t total_tiles = off + tiles;
-            // counts that do not add up to n (a wrapped counter) are never acted on
-            const bool ok = s_max <= cap && hdr->overflow == 0 && s_bstart[kHybBuckets] == n && force_mode != kHybFallback;
+            const uint32_t total_big_tiles = bigoff_t + bigtiles;
+            // Counts that do not add up to n are never acted on.  More oversized sub-buckets than the
+            // table holds, or more than a quarter of the pairs in them (those pairs are moved four
+            // times and counted twice): the ordinary passes are the better schedule.
+            // Nor is a call whose local sort was set up to stage 6 bytes per pair when the keys turn
+            // out to differ above the sorted range (the ordinary passes carry any bits along).
+            const bool ok = hdr->overflow == 0 && s_bstart[kHybBuckets] == n && force_mode != kHybFallback &&
+                            total_big <= kHybMaxBig && s_bigpairs <= n / 4u && !(compact_ok != 0u && hdr->high_vary != 0u);
             tb->first_tile[kHybBuckets] = total_tiles;
+            tb->big_first_tile[kHybMaxBig] = total_big_tiles;
             hdr->num_tiles_b = ok ? total_tiles : 0u;
-            hdr->max_sub = hdr->overflow ? 0xFFFFFFFFu : s_max;  // a histogram that stopped early has no counts to report
+            hdr->num_big = ok ? total_big : 0u;
+            hdr->num_tiles_big = ok ? total_big_tiles : 0u;
+            hdr->big_pairs = s_bigpairs;
+            hdr->max_sub = s_max;
             hdr->mode = ok ? kHybRun : kHybFallback;
         }
     }
 }
 
+// ---- the oversized sub-buckets: digit counts and run positions -------------------------------
+// counts of the two local digits of every oversized sub-bucket, tile by tile of the passes that
+// will move them (a tile never straddles two of them)
+__global__ __launch_bounds__(1024) void hybrid_big_histogram_kernel(const uint32_t* __restrict__ keys,
+                                                                     const HybridTables* __restrict__ tb, HybridCleared* hc,
+                                                                     uint32_t tile_items, uint32_t shift, uint32_t bits1,
+                                                                     uint32_t bits2)
+{
+    __shared__ uint32_t s_h[2][256];
+    __shared__ uint32_t s_seg[3];
+    if (hc->hdr.mode != kHybRun) return;  // uniform
+    const uint32_t num_tiles = hc->hdr.num_tiles_big;
+    const uint32_t tid = threadIdx.x;
+    uint32_t ft0 = 0, ft1 = 0, bs0 = 0, bs1 = 0;
+    if (tid < kHybMaxBig && num_tiles != 0u) {
+        ft0 = tb->big_first_tile[tid];
+        ft1 = tb->big_first_tile[tid + 1];
+        bs0 = tb->big_start[tid];
+        bs1 = tb->big_end[tid];
+    }
+    for (uint32_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+        if (tid < 512) (&s_h[0][0])[tid] = 0;
+        if (tid < kHybMaxBig && ft0 <= tile && tile < ft1) {  // exactly one thread
+            s_seg[0] = tid;
+            s_seg[1] = bs0 + (tile - ft0) * tile_items;
+            s_seg[2] = bs1;
+        }
+        __syncthreads();
+        const uint32_t seg = s_seg[0], base = s_seg[1];
+        const uint32_t left = s_seg[2] - base;
+        const uint32_t cnt = left < tile_items ? left : tile_items;
+        for (uint32_t i = tid; i < cnt; i += 1024) {
+            const uint32_t k = keys[base + i];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t d = h == 0 ? __builtin_amdgcn_ubfe(k, shift, bits1) : __builtin_amdgcn_ubfe(k, shift + bits1, bits2);
+                // the keys of an oversized sub-bucket are often few distinct values: one add for
+                // the lanes that hold the first lane's digit
+                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+                const unsigned long long same = __builtin_amdgcn_uicmp(d, d0, 32 /* == */);
+                const uint32_t group = static_cast<uint32_t>(__popcll(same));
+                if (group >= 8u && d == d0) {
+                    if (lanes_below(static_cast<uint32_t>(same), static_cast<uint32_t>(same >> 32)) == 0u) atomicAdd(&s_h[h][d0], group);
+                } else {
+                    atomicAdd(&s_h[h][d], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 512) {
+            const uint32_t cc = (&s_h[0][0])[tid];
+            if (cc) atomicAdd(&hc->big_hist[seg][tid >> 8][tid & 255u], cc);
+        }
+        __syncthreads();  // s_h and s_seg are rewritten for the next tile
+    }
+}
+
+// big_hist[j][h][d]: count -> position in the array of the run of digit d of oversized sub-bucket j
+// in the pass on digit h (both passes stay inside the sub-bucket's own range)
+__global__ __launch_bounds__(256) void hybrid_big_scan_kernel(const HybridTables* __restrict__ tb, HybridCleared* hc)
+{
+    __shared__ uint32_t s_w[2][4];
+    if (hc->hdr.mode != kHybRun || blockIdx.x >= hc->hdr.num_big) return;  // uniform
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t start = tb->big_start[seg];
+    uint32_t cnt[2], incl[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        cnt[h] = hc->big_hist[seg][h][tid];
+        incl[h] = cnt[h];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl[h], o);
+            if (lane >= static_cast<uint32_t>(o)) incl[h] += y;
+        }
+        if (lane == 63) s_w[h][wave] = incl[h];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t off = incl[h] - cnt[h];
+        for (uint32_t w = 0; w < 4; ++w)
+            if (w < wave) off += s_w[h][w];
+        hc->big_hist[seg][h][tid] = start + off;
+    }
+}
+
 // ---- chained-scan passes that the device switches on or off --------------------------------
-// The digit pass of mrs_radix_pass.hpp behind a gate (hdr->mode == run_if_mode), over the whole
-// array (pass A, or one of the plan's ordinary passes when the device chose those) or, SEG, over
-// the buckets pass A made: tile t belongs to the bucket b with first_tile[b] <= t < first_tile[b+1],
-// covers TILE elements from bucket_start[b] + (t - first_tile[b]) * TILE (fewer in the bucket's
-// last tile), and its chained scan starts at first_tile[b] with the sub-bucket starts of b as
-// digit bases.  PERSISTENT: the workgroup draws tiles until none is left (same time per pass as a
-// workgroup per tile, 0.86-0.88 ms at 2^28, also when the next ticket is drawn during the write-out:
-// the hand-over from tile to tile is not what bounds a pass; but a switched-off launch costs 0.005 ms
-// instead of 0.1, and one that runs holds every compute unit until the pass ends, which a collective
-// waiting on another stream feels).
+// The digit pass of mrs_radix_pass.hpp behind a gate.  One launch serves both schedules, which
+// never run in the same call: if hdr->mode == kHybRun the pass `run` describes, over the whole
+// array (pass A) or, with a segment table, over segments of it (pass B: the buckets pass A made;
+// the two passes over the oversized sub-buckets): tile t belongs to the segment s with
+// first_tile[s] <= t < first_tile[s+1], covers TILE elements from start[s] + (t - first_tile[s]) *
+// TILE (fewer in the segment's last tile), and its chained scan starts at first_tile[s] with the
+// segment's own digit bases.  If hdr->mode == kHybFallback (and the launch is DUAL) the pass `other`
+// describes over the whole array: one of the plan's ordinary passes.  A launch that has
+// nothing to do in the mode the device chose costs its workgroups' start and end, so the fewer
+// launches the better: four launches carry A, B and the two oversized passes of one schedule and
+// the four ordinary passes of the other.
+// PERSISTENT: the workgroup draws tiles until none is left (same time per pass as a workgroup
+// per tile within 1 %, also when the next ticket is drawn during the write-out: the hand-over from
+// tile to tile is not what bounds a pass; but a launch with nothing to do costs 0.005 ms instead of
+// 0.1, and one that runs holds every compute unit until the pass ends, which a collective waiting
+// on another stream feels).
+// One schedule's pass: every access to its description is an access to kernel arguments known at
+// compile time (a description picked at run time from two made every pass 15 to 30 % slower).
 template <bool SEG, bool PERSISTENT, int MAP, int THREADS, int KPT>
-__global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs a, const HybridHeader* __restrict__ hdr,
-                                                                  const HybridTables* __restrict__ tb,
-                                                                  const uint32_t run_if_mode)
+__device__ __forceinline__ void gated_pass(const PassArgs& a, const SegmentTable& seg,
+                                           PassShared<8, THREADS, KPT, uint32_t, uint32_t>& sh, uint32_t (&s_seg)[4])
 {
     using S = PassShared<8, THREADS, KPT, uint32_t, uint32_t>;
-    __shared__ S sh;
-    __shared__ uint32_t s_seg[4];
     uint32_t tid = threadIdx.x;
-    const uint32_t mode = hdr->mode;  // uniform
-    if (PERSISTENT && mode != run_if_mode) return;
-    const uint32_t num_tiles = SEG ? hdr->num_tiles_b : a.num_tiles;
+    const uint32_t num_tiles = SEG ? *seg.num_tiles : a.num_tiles;
+    // no ticket is drawn for a pass without tiles (the usual state of the passes over oversized
+    // sub-buckets: with die-aware tickets a workgroup would try all eight lists in turn)
+    if (num_tiles == 0u) return;  // uniform
     uint32_t ft0 = 0, ft1 = 0, bs0 = 0, bs1 = 0;
     if constexpr (SEG) {
-        if (tid < kHybBuckets) {
-            ft0 = tb->first_tile[tid];
-            ft1 = tb->first_tile[tid + 1];
-            bs0 = tb->bucket_start[tid];
-            bs1 = tb->bucket_start[tid + 1];
+        if (tid < kHybBuckets) {  // a segment table has at most 256 segments
+            ft0 = seg.first_tile[tid];
+            ft1 = seg.first_tile[tid + 1];
+            bs0 = seg.start[tid];
+            bs1 = seg.end[tid];
         }
     }
     for (;;) {
@@ -283,14 +507,8 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
             // registers are needed inside the tile: 19 spilled values and 9 % of the time otherwise)
             asm volatile("" : "+v"(tid));
         }
-        // The gate word and the first ticket travel together: a workgroup of a launch that runs
-        // does not wait for one after the other, and one of a launch that is switched off leaves
-        // as soon as the word is there (having wasted a ticket of a counter nobody else reads).
-        Ticket ticket{0, 0};
-        if (tid == 0) ticket = ticket_issue(a);
-        if (mode != run_if_mode) return;  // uniform
         if (tid == 0) {
-            sh.tile = ticket_tile(a, ticket, num_tiles);
+            sh.tile = ticket_tile(a, ticket_issue(a), num_tiles);
             sh.abort = 0;
         }
         __syncthreads();
@@ -301,18 +519,18 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
         // a workgroup without a tile has left by now.
         for (int j = tid & 63; j < S::RADIX; j += 64) sh.wave_hist[tid >> 6][j] = 0;
         if constexpr (SEG) {
-            if (tid < kHybBuckets && ft0 <= tile && tile < ft1) {  // exactly one thread: empty buckets have ft0 == ft1
+            if (tid < kHybBuckets && ft0 <= tile && tile < ft1) {  // exactly one thread: empty segments have ft0 == ft1
                 s_seg[0] = tid;
                 s_seg[1] = ft0;
                 s_seg[2] = bs0;
                 s_seg[3] = bs1;
             }
             __syncthreads();
-            const uint32_t seg = s_seg[0], first = s_seg[1], start = s_seg[2], end = s_seg[3];
+            const uint32_t which = s_seg[0], first = s_seg[1], start = s_seg[2], end = s_seg[3];
             const uint32_t base = start + (tile - first) * static_cast<uint32_t>(S::TILE);
             const uint32_t remaining = end - base;
             PassArgs b = a;
-            b.digit_base = tb->sub_start + seg * (a.mask + 1u);  // the bucket's sub-buckets, a.mask + 1 of them
+            b.digit_base = seg.digit_base + which * seg.digit_stride;
             if (remaining >= static_cast<uint32_t>(S::TILE))
                 process_tile<kModeOnesweep, kRankAtomic, MAP, true, uint32_t>(b, sh, tile, S::TILE, base, first, tid);
             else
@@ -333,77 +551,136 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
     }
 }
 
+// SEG: `run` is a pass over the segments of `seg`.  DUAL: `other` exists (persistent launches only).
+template <bool SEG, bool DUAL, bool PERSISTENT, int MAP, int THREADS, int KPT>
+__global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs run, const SegmentTable seg,
+                                                                  const PassArgs other, const HybridHeader* __restrict__ hdr)
+{
+    using S = PassShared<8, THREADS, KPT, uint32_t, uint32_t>;
+    __shared__ S sh;
+    __shared__ uint32_t s_seg[4];
+    const uint32_t mode = hdr->mode;  // uniform
+    if (mode == kHybRun) {
+        gated_pass<SEG, PERSISTENT, MAP, THREADS, KPT>(run, seg, sh, s_seg);
+    } else if constexpr (DUAL) {
+        if (mode == kHybFallback) gated_pass<false, PERSISTENT, kMapNone, THREADS, KPT>(other, seg, sh, s_seg);
+    }
+}
+
 // ---- local sort -----------------------------------------------------------------------------
-// A workgroup takes sub-buckets blockIdx.x, blockIdx.x + gridDim.x, ...: at most THREADS * KPT
-// pairs each (the decision kernel saw to that), loaded in the element order of the digit pass
-// (wave w owns a contiguous slice, item i of lane l is element w*64*ku + i*64 + l, ku = items per
-// thread of THIS sub-bucket), sorted by two stable counting passes through LDS on bits
-// [shift, shift + bits1) and [shift + bits1, shift + bits1 + bits2), each at most 8 bits wide,
+// A workgroup takes sub-buckets blockIdx.x, blockIdx.x + gridDim.x, ...: those of at most
+// THREADS * KPT pairs (larger ones are the segmented passes'), loaded in the element order of the
+// digit pass (wave w owns a contiguous slice, item i of lane l is element w*64*ku + i*64 + l,
+// ku = items per thread of THIS sub-bucket), sorted by two stable counting passes through LDS on
+// bits [shift, shift + bits1) and [shift + bits1, shift + bits1 + bits2), each at most 8 bits wide,
 // ranked like the digit pass (returning LDS atomics on per-wave counters, lane order), and
 // written back over the sub-bucket, which nobody else touches.
+// COMPACT: a pair is staged as its low 16 key bits and its payload, 6 bytes instead of 8, so the
+// same 60 KiB of LDS hold 10240 pairs instead of 7680; the rest of the key is the same for every
+// key of the sub-bucket (key_shift <= 16, and the histogram kernel found no differing bits above
+// the sorted range: the decision kernel refuses the schedule otherwise) and is put back at the
+// write-out.
+// Inclusive prefix sum over the 64 lanes of a wave whose lanes are all active: inside rows of 16
+// lanes by DPP row shifts (a lane without a source lane adds 0), then the totals of the rows
+// before it (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six dependent adds,
+// against six round trips through the LDS crossbar for the same scan by __shfl_up.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
+{
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xA, 0xF, false);  // row_bcast:15
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xC, 0xF, false);  // row_bcast:31
+    return x;
+}
+
 constexpr uint32_t kLocalMinGrid = 256;  // so that a workgroup has at most this many sub-buckets
 constexpr uint32_t kLocalMaxPerGroup = kHybSubs / kLocalMinGrid;
+constexpr int kLocalStageBytes = kHybLocalThreads * kHybLocalKptFull * 8;
+static_assert(kLocalStageBytes >= kHybLocalThreads * kHybLocalKptCompact * 6, "both stagings fit the same LDS");
 
-template <int THREADS, int KPT>
+template <int THREADS, int KPT, bool COMPACT>
 __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t* __restrict__ keys,
                                                                      uint32_t* __restrict__ vals,
                                                                      const HybridHeader* __restrict__ hdr,
                                                                      const HybridTables* __restrict__ tb,
                                                                      const uint32_t shift, const uint32_t bits1,
-                                                                     const uint32_t bits2, const uint32_t num_subs)
+                                                                     const uint32_t bits2, const uint32_t num_subs,
+                                                                     const uint32_t key_shift)
 {
     constexpr int WAVES = THREADS / 64;
     constexpr int RADIX = 256;
+    constexpr uint32_t CAP = THREADS * KPT;
     static_assert(THREADS >= RADIX, "one thread per digit in the scan");
-    __shared__ __attribute__((aligned(16))) uint2 s_stage[THREADS * KPT];  // 60 KiB at 512 x 15: two workgroups fit a compute unit's 160 KiB
+    // 60 KiB: two workgroups fit a compute unit's 160 KiB.  Full: (key, payload) per slot.
+    // Compact: CAP payloads, then CAP 16-bit keys.
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLocalStageBytes];
     __shared__ uint32_t s_hist[2][WAVES][RADIX];
     __shared__ uint32_t s_wsum[2][4];
     __shared__ uint32_t s_first[kLocalMaxPerGroup], s_count[kLocalMaxPerGroup];
     if (hdr->mode != kHybRun || blockIdx.x >= num_subs) return;  // uniform
+    uint2* const s_pair = reinterpret_cast<uint2*>(s_raw);
+    uint32_t* const s_val = reinterpret_cast<uint32_t*>(s_raw);
+    unsigned short* const s_key16 = reinterpret_cast<unsigned short*>(s_raw + CAP * 4);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t shifts[2] = {shift, shift + bits1};
     const uint32_t widths[2] = {bits1, bits2};
 
     // element i of this thread in a sub-bucket of `count` pairs, `per` to a thread
     auto element = [&](uint32_t per, int i) __attribute__((always_inline)) { return wave * 64u * per + lane + i * 64u; };
+    // KU: items per thread the code is unrolled for (several copies for sub-buckets of different
+    // sizes, chosen per sub-bucket, cost 30 spilled registers at the joins: there is one copy).
     // Straight-line on purpose: every item is loaded, items past the sub-bucket's end from its
     // first element (one cache line for the whole wave; the value is never used).  Conditional
     // loads into the arrays made the compiler copy whole arrays at every join.
-    auto load_bucket = [&](uint32_t (&key)[KPT], uint32_t (&val)[KPT], uint32_t first, uint32_t count) __attribute__((always_inline)) {
-        if (count == 0) return;  // uniform; sort_bucket does not look at the registers either
+    auto load_bucket = [&](auto ku_tag, uint32_t (&key)[KPT], uint32_t (&val)[KPT], uint32_t first, uint32_t count) __attribute__((always_inline)) {
+        constexpr int KU = decltype(ku_tag)::value;
         const uint32_t per = (count + THREADS - 1) / THREADS;
         const uint32_t* __restrict__ kin = keys + first;
         const uint32_t* __restrict__ vin = vals + first;
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
+        for (int i = 0; i < KU; ++i) {
             const uint32_t e = element(per, i);
             const uint32_t ec = (static_cast<uint32_t>(i) < per && e < count) ? e : 0u;
             key[i] = kin[ec];  // nontemporal loads measured 7 % slower
             val[i] = vin[ec];
         }
     };
-    // sorts the `cnt` pairs held in (key, val) and writes them over [start, start + cnt)
-    auto sort_bucket = [&](uint32_t (&key)[KPT], uint32_t (&val)[KPT], const uint32_t start, const uint32_t cnt) __attribute__((always_inline)) {
-        if (cnt == 0) return;  // uniform
+    // sorts the `cnt` pairs held in (key, val) into the stage; returns the key bits every key of the
+    // sub-bucket has (COMPACT), which the write-out puts back
+    auto sort_in_stage = [&](auto ku_tag, uint32_t (&key)[KPT], uint32_t (&val)[KPT], const uint32_t cnt) __attribute__((always_inline)) -> uint32_t {
+        constexpr int KU = decltype(ku_tag)::value;
         const uint32_t ku = (cnt + THREADS - 1) / THREADS;
-        PackedPos<KPT> pos;  // ranks and slots are below 2^13: two to a register
-        for (int j = tid; j < 2 * WAVES * RADIX; j += THREADS) (&s_hist[0][0][0])[j] = 0;
-        __syncthreads();  // the counters are zero (and every wave has left the previous write-out)
+        // item 0 of thread 0 always exists
+        uint32_t high = 0;
+        if constexpr (COMPACT) high = __builtin_amdgcn_readfirstlane(key[0]) >> key_shift << key_shift;
+        PackedPos<KU> pos;  // ranks and slots are below 2^14: two to a register
+        // The counters are zero: cleared before the first sub-bucket and then, each set, right
+        // after its last use below; between that and the next use lie the barriers of the other
+        // digit's phase.  The stage is not written before three barriers from here, behind which
+        // every wave has left the previous write-out.
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const uint32_t sh = shifts[h], wd = widths[h];
             if (h == 1) {
                 // the order pass 1 left in LDS, read back slice by slice
 #pragma unroll
-                for (int i = 0; i < KPT; ++i) {
+                for (int i = 0; i < KU; ++i) {
                     const uint32_t e = element(ku, i);
-                    const uint2 kv = s_stage[(static_cast<uint32_t>(i) < ku && e < cnt) ? e : 0u];  // straight-line, as the loads
-                    key[i] = kv.x;
-                    val[i] = kv.y;
+                    const uint32_t ec = (static_cast<uint32_t>(i) < ku && e < cnt) ? e : 0u;  // straight-line, as the loads
+                    if constexpr (COMPACT) {
+                        key[i] = s_key16[ec];
+                        val[i] = s_val[ec];
+                    } else {
+                        const uint2 kv = s_pair[ec];
+                        key[i] = kv.x;
+                        val[i] = kv.y;
+                    }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < KPT; ++i) {
+            for (int i = 0; i < KU; ++i) {
                 uint32_t r = 0;
                 if (static_cast<uint32_t>(i) < ku && element(ku, i) < cnt)
                     r = atomicAdd(&s_hist[h][wave][__builtin_amdgcn_ubfe(key[i], sh, wd)], 1u);
@@ -421,12 +698,7 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
                     c[w] = tot;
                     tot += x;
                 }
-                incl = tot;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t y = __shfl_up(incl, o);
-                    if (lane >= static_cast<uint32_t>(o)) incl += y;
-                }
+                incl = wave_inclusive_sum(tot);  // waves 0 to 3, all lanes
                 if (lane == 63) s_wsum[h][wave] = incl;
             }
             __syncthreads();  // the per-wave parts wait in registers for the digit's offset
@@ -439,50 +711,78 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
             }
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                if (static_cast<uint32_t>(i) < ku && element(ku, i) < cnt)
-                    s_stage[pos.get(i) + s_hist[h][wave][__builtin_amdgcn_ubfe(key[i], sh, wd)]] = make_uint2(key[i], val[i]);
+            for (int i = 0; i < KU; ++i) {
+                if (static_cast<uint32_t>(i) < ku && element(ku, i) < cnt) {
+                    const uint32_t slot = pos.get(i) + s_hist[h][wave][__builtin_amdgcn_ubfe(key[i], sh, wd)];
+                    if constexpr (COMPACT) {
+                        s_key16[slot] = static_cast<unsigned short>(key[i]);
+                        s_val[slot] = val[i];
+                    } else {
+                        s_pair[slot] = make_uint2(key[i], val[i]);
+                    }
+                }
             }
             __syncthreads();
+            for (int j = tid; j < WAVES * RADIX; j += THREADS) (&s_hist[h][0][0])[j] = 0;  // for the next sub-bucket
         }
-        // write-out, two slots per lane: one 16-byte LDS read, one 8-byte store each for keys and
-        // payload (a sub-bucket starts at any 4-byte boundary; gfx950 serves the wider store there).
-        // Four slots and 16-byte stores measured 2 % slower.
+        return high;
+    };
+    // the sorted stage over [start, start + cnt), two slots per lane: one 8-byte store each for keys
+    // and payload (a sub-bucket starts at any 4-byte boundary; gfx950 serves the wider store there).
+    // Four slots and 16-byte stores measured 2 % slower.
+    auto write_out = [&](const uint32_t start, const uint32_t cnt, const uint32_t high) __attribute__((always_inline)) {
         uint32_t* __restrict__ kout = keys + start;
         uint32_t* __restrict__ vout = vals + start;
         for (uint32_t s2 = 2u * tid; s2 < cnt; s2 += 2u * THREADS) {
-            if (s2 + 1 < cnt) {
-                const uint4 q = *reinterpret_cast<const uint4*>(&s_stage[s2]);
-                *reinterpret_cast<uint2*>(kout + s2) = make_uint2(q.x, q.z);
-                *reinterpret_cast<uint2*>(vout + s2) = make_uint2(q.y, q.w);
+            if constexpr (COMPACT) {
+                const uint32_t kk = *reinterpret_cast<const uint32_t*>(&s_key16[s2]);  // s2 is even: two keys in one word
+                if (s2 + 1 < cnt) {
+                    const uint2 vv = *reinterpret_cast<const uint2*>(&s_val[s2]);
+                    *reinterpret_cast<uint2*>(kout + s2) = make_uint2(high | (kk & 0xFFFFu), high | (kk >> 16));
+                    *reinterpret_cast<uint2*>(vout + s2) = vv;
+                } else {
+                    kout[s2] = high | (kk & 0xFFFFu);
+                    vout[s2] = s_val[s2];
+                }
             } else {
-                const uint2 kv = s_stage[s2];
-                kout[s2] = kv.x;
-                vout[s2] = kv.y;
+                if (s2 + 1 < cnt) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(&s_pair[s2]);
+                    *reinterpret_cast<uint2*>(kout + s2) = make_uint2(q.x, q.z);
+                    *reinterpret_cast<uint2*>(vout + s2) = make_uint2(q.y, q.w);
+                } else {
+                    const uint2 kv = s_pair[s2];
+                    kout[s2] = kv.x;
+                    vout[s2] = kv.y;
+                }
             }
         }
     };
 
     // This workgroup's sub-buckets are blockIdx.x, + gridDim.x, ...: their bounds go to LDS once
-    // (a scalar load inside the loop would be waited for at the next LDS access).  Two register
-    // sets take turns: while one sub-bucket is sorted and written out, the pairs of the next are
-    // already on their way into the other set, so the workgroup always has loads in flight.
+    // (a scalar load inside the loop would be waited for at the next LDS access); one that does not
+    // fit is entered as empty (the segmented passes sort it).  The pairs of the next sub-bucket are
+    // requested as soon as the second scatter has emptied the registers, so they travel while the
+    // current one is written out (two register sets, with the request before the sort, measured the
+    // same time and cost 60 to 80 registers more).
     const uint32_t mine = (num_subs - 1u - blockIdx.x) / gridDim.x + 1u;  // blockIdx.x < num_subs <= kHybSubs
     for (uint32_t j = tid; j < mine; j += THREADS) {
         const uint32_t which = blockIdx.x + j * gridDim.x;
-        s_first[j] = tb->sub_start[which];
-        s_count[j] = tb->sub_start[which + 1] - tb->sub_start[which];
+        const uint32_t first = tb->sub_start[which];
+        const uint32_t count = tb->sub_start[which + 1] - first;
+        s_first[j] = first;
+        s_count[j] = count <= CAP ? count : 0u;
     }
+    for (int j = tid; j < 2 * WAVES * RADIX; j += THREADS) (&s_hist[0][0][0])[j] = 0;
     __syncthreads();
-    uint32_t key_a[KPT], val_a[KPT], key_b[KPT], val_b[KPT];
-    load_bucket(key_a, val_a, s_first[0], s_count[0]);
-    for (uint32_t j = 0;;) {
-        if (j + 1 < mine) load_bucket(key_b, val_b, s_first[j + 1], s_count[j + 1]);
-        sort_bucket(key_a, val_a, s_first[j], s_count[j]);
-        if (++j >= mine) break;
-        if (j + 1 < mine) load_bucket(key_a, val_a, s_first[j + 1], s_count[j + 1]);
-        sort_bucket(key_b, val_b, s_first[j], s_count[j]);
-        if (++j >= mine) break;
+    const std::integral_constant<int, KPT> all_items{};
+    uint32_t key[KPT], val[KPT];
+    if (s_count[0] != 0u) load_bucket(all_items, key, val, s_first[0], s_count[0]);
+    for (uint32_t j = 0; j < mine; ++j) {
+        const uint32_t first = s_first[j], count = s_count[j];
+        uint32_t high = 0;
+        if (count != 0u) high = sort_in_stage(all_items, key, val, count);
+        if (j + 1 < mine && s_count[j + 1] != 0u) load_bucket(all_items, key, val, s_first[j + 1], s_count[j + 1]);
+        if (count != 0u) write_out(first, count, high);
     }
 }
 
@@ -503,72 +803,108 @@ int hybrid_local_sort_grid(int num_cus)
     // 78 KiB of LDS each: two per compute unit
     const int g = num_cus * 2;
     return g < static_cast<int>(kLocalMinGrid) ? static_cast<int>(kLocalMinGrid) : g;
-}  // 80 KiB of LDS each: two per compute unit
+}
 
 int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t bits, bool windowed, uint32_t window_base,
-                            int grid, uint32_t* packed, HybridHeader* hdr, hipStream_t s)
+                            uint32_t end_bit, int grid, uint32_t* packed, HybridCleared* hc, hipStream_t s)
 {
     const ProfilerRange range("Histogram calculation");  // src/main.rs:597
     const uint32_t vectors = (reinterpret_cast<uintptr_t>(keys) & 15u) ? 0u : n / 4u;
-    hipLaunchKernelGGL(hybrid_histogram_kernel, dim3(grid), dim3(1024), 0, s, keys, n, vectors, shift, bits, packed, hdr,
-                       kHybLocalCap, window_base, windowed ? 1u : 0u);
+    hipLaunchKernelGGL(hybrid_histogram_kernel, dim3(grid), dim3(1024), 0, s, keys, n, vectors, shift, bits, packed, hc,
+                       window_base, windowed ? 1u : 0u, end_bit);
     MRS_CHECK_LAUNCH("hybrid_histogram_kernel");
     return MRS_OK;
 }
 
-int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridHeader* hdr, uint32_t n,
-                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, hipStream_t s)
+int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridCleared* hc, uint32_t n,
+                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, bool compact_ok, hipStream_t s)
 {
     if (sub_bits < 6 || sub_bits > 8) return fail(MRS_ERR_UNSUPPORTED, "a bucket has 64 to 256 sub-buckets");
     const ProfilerRange range("Small Prefix Sum");  // src/main.rs:625
-    hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(kHybPackedWords / 64), dim3(256), 0, s, packed, grid, tables->counts);
+    hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(kHybPackedWords / 64), dim3(256), 0, s, packed, grid, hc->spill, tables->counts);
     MRS_CHECK_LAUNCH("hybrid_reduce_kernel");
-    hipLaunchKernelGGL(hybrid_scan_kernel, dim3(1), dim3(1024), 0, s, tables, hdr, n, tile_items, kHybLocalCap, force_mode, sub_bits);
+    hipLaunchKernelGGL(hybrid_scan_kernel, dim3(1), dim3(1024), 0, s, tables, hc, n, tile_items, force_mode, sub_bits,
+                       compact_ok ? 1u : 0u);
     MRS_CHECK_LAUNCH("hybrid_scan_kernel");
     return MRS_OK;
 }
 
-template <bool SEG, bool PERSISTENT, int MAP>
-static int launch_pass_shape(int threads, int kpt, const PassArgs& a, const HybridHeader* hdr, const HybridTables* tables,
-                             uint32_t run_if_mode, uint32_t grid, hipStream_t s)
+template <bool SEG, bool DUAL, bool PERSISTENT, int MAP>
+static int launch_pass_shape(int threads, int kpt, const PassArgs& run, const SegmentTable& seg, const PassArgs& other,
+                             const HybridHeader* hdr, uint32_t grid, hipStream_t s)
 {
     if (threads == 1024 && kpt == 32)
-        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, PERSISTENT, MAP, 1024, 32>), dim3(grid), dim3(1024), 0, s, a, hdr, tables, run_if_mode);
+        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 1024, 32>), dim3(grid), dim3(1024), 0, s, run, seg, other, hdr);
     else if (threads == 512 && kpt == 8)
-        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, PERSISTENT, MAP, 512, 8>), dim3(grid), dim3(512), 0, s, a, hdr, tables, run_if_mode);
+        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 512, 8>), dim3(grid), dim3(512), 0, s, run, seg, other, hdr);
     else
         return fail(MRS_ERR_UNSUPPORTED, "no gated pass kernel for %d threads x %d keys per thread", threads, kpt);
     MRS_CHECK_LAUNCH("hybrid_pass_kernel");
     return MRS_OK;
 }
 
-int hybrid_launch_pass(bool segmented, bool persistent, bool windowed, int threads, int kpt, const PassArgs& a,
-                       const HybridHeader* hdr, const HybridTables* tables, uint32_t run_if_mode, uint32_t grid, hipStream_t s)
+int hybrid_launch_pass(const PassArgs* run, const SegmentTable* seg, const PassArgs* other, bool persistent, bool windowed,
+                       int threads, int kpt, const HybridHeader* hdr, uint32_t grid, hipStream_t s)
 {
-    if (a.wide_status) return fail(MRS_ERR_UNSUPPORTED, "gated passes use 32-bit tile status words");
+    if (!run && !other) return fail(MRS_ERR_INVALID_ARGUMENT, "a gated pass needs at least one description");
+    if ((run && run->wide_status) || (other && other->wide_status))
+        return fail(MRS_ERR_UNSUPPORTED, "gated passes use 32-bit tile status words");
     const ProfilerRange range("Indexing");  // src/main.rs:658
     if (grid == 0) grid = 1;
-    if (persistent) {  // the plan's ordinary passes, or pass B of a sort that shares the device with nothing: plain digits
+    // a `run` that is not given has no tiles, so it does nothing in its mode
+    const PassArgs none{};
+    const PassArgs& r = run ? *run : none;
+    const PassArgs& o = other ? *other : none;
+    const bool segmented = run && seg;
+    const SegmentTable table = segmented ? *seg : SegmentTable{};
+    if (persistent) {  // passes of a sort that shares the device with nothing: plain bit-field digits
         if (windowed) return fail(MRS_ERR_UNSUPPORTED, "persistent gated passes take plain bit-field digits");
-        return segmented ? launch_pass_shape<true, true, kMapNone>(threads, kpt, a, hdr, tables, run_if_mode, grid, s)
-                         : launch_pass_shape<false, true, kMapNone>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
+        if (other)
+            return segmented ? launch_pass_shape<true, true, true, kMapNone>(threads, kpt, r, table, o, hdr, grid, s)
+                             : launch_pass_shape<false, true, true, kMapNone>(threads, kpt, r, table, o, hdr, grid, s);
+        return segmented ? launch_pass_shape<true, false, true, kMapNone>(threads, kpt, r, table, o, hdr, grid, s)
+                         : launch_pass_shape<false, false, true, kMapNone>(threads, kpt, r, table, o, hdr, grid, s);
     }
+    if (other) return fail(MRS_ERR_UNSUPPORTED, "a pass with a workgroup per tile serves one schedule");
     if (windowed)
-        return segmented ? launch_pass_shape<true, false, kMapWindow>(threads, kpt, a, hdr, tables, run_if_mode, grid, s)
-                         : launch_pass_shape<false, false, kMapWindow>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
-    return segmented ? launch_pass_shape<true, false, kMapNone>(threads, kpt, a, hdr, tables, run_if_mode, grid, s)
-                     : launch_pass_shape<false, false, kMapNone>(threads, kpt, a, hdr, tables, run_if_mode, grid, s);
+        return segmented ? launch_pass_shape<true, false, false, kMapWindow>(threads, kpt, r, table, o, hdr, grid, s)
+                         : launch_pass_shape<false, false, false, kMapWindow>(threads, kpt, r, table, o, hdr, grid, s);
+    return segmented ? launch_pass_shape<true, false, false, kMapNone>(threads, kpt, r, table, o, hdr, grid, s)
+                     : launch_pass_shape<false, false, false, kMapNone>(threads, kpt, r, table, o, hdr, grid, s);
+}
+
+int hybrid_launch_big_histogram(const uint32_t* keys, const HybridTables* tables, HybridCleared* hc, uint32_t tile_items,
+                                uint32_t shift, uint32_t bits1, uint32_t bits2, int grid, hipStream_t s)
+{
+    if (bits1 == 0 || bits1 > 8 || bits2 == 0 || bits2 > 8)
+        return fail(MRS_ERR_UNSUPPORTED, "oversized sub-buckets are sorted on two digits of 1 to 8 bits");
+    {
+        const ProfilerRange range("Histogram calculation");  // src/main.rs:597
+        hipLaunchKernelGGL(hybrid_big_histogram_kernel, dim3(grid < 1 ? 1 : grid), dim3(1024), 0, s, keys, tables, hc, tile_items,
+                           shift, bits1, bits2);
+        MRS_CHECK_LAUNCH("hybrid_big_histogram_kernel");
+    }
+    const ProfilerRange range("Small Prefix Sum");  // src/main.rs:625
+    hipLaunchKernelGGL(hybrid_big_scan_kernel, dim3(kHybMaxBig), dim3(256), 0, s, tables, hc);
+    MRS_CHECK_LAUNCH("hybrid_big_scan_kernel");
+    return MRS_OK;
 }
 
 int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,
-                             uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, int grid, hipStream_t s)
+                             uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, uint32_t key_shift,
+                             bool compact_ok, int grid, hipStream_t s)
 {
     if (num_subs == 0 || num_subs > kHybSubs) return fail(MRS_ERR_UNSUPPORTED, "at most 65536 sub-buckets");
     if (bits1 == 0 || bits1 > 8 || bits2 == 0 || bits2 > 8)
         return fail(MRS_ERR_UNSUPPORTED, "the local sort takes two digits of 1 to 8 bits");
+    if (compact_ok && key_shift > 16) return fail(MRS_ERR_INVALID_ARGUMENT, "6-byte staging needs the sub-bucket's bits to start at bit 16 or below");
     const ProfilerRange range("Local sort");
-    hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreads, kHybLocalKpt>), dim3(grid), dim3(kHybLocalThreads), 0, s,
-                       keys, vals, hdr, tables, shift, bits1, bits2, num_subs);
+    if (compact_ok)
+        hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreads, kHybLocalKptCompact, true>), dim3(grid), dim3(kHybLocalThreads),
+                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift);
+    else
+        hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreads, kHybLocalKptFull, false>), dim3(grid), dim3(kHybLocalThreads),
+                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift);
     MRS_CHECK_LAUNCH("hybrid_local_sort_kernel");
     return MRS_OK;
 }

@@ -8,14 +8,24 @@
 //   pass B  one chained-scan scatter by the next 7 or 8 bits, every bucket a chain of its own
 //           (2^14 to 2^16 sub-buckets; tiles never straddle a bucket);
 //   local   every sub-bucket is loaded into LDS by one workgroup, sorted there by the remaining
-//           9..16 bits in two stable counting passes, and written back in place, sequentially.
-// The split (14, 15 or 16 bits for A and B together) is the host's, from n: sub-buckets of about
-// 4096 pairs keep the local sort's workgroups busy, and the local sort takes at most 16 bits.
-// It needs sub-buckets that fit a workgroup, which only the device can know (the host never reads
-// a key), so a 16-bit histogram taken before pass A decides on the device: if any sub-bucket
-// exceeds the capacity, the three kernels above return at once and the four least-significant-
-// digit-first passes of the plan run instead; otherwise those return at once.  Both schedules end
-// on the same side (A: a -> b, B: b -> a, local: in place; four passes: a again).
+//           2..16 bits in two stable counting passes, and written back in place, sequentially.
+// The split (14, 15 or 16 bits for A and B together) is the host's, from n: sub-buckets of a few
+// thousand pairs keep the local sort's workgroups busy, and the local sort takes at most 16 bits.
+//
+// A sub-bucket must fit a workgroup, which only the device can know (the host never reads a key),
+// so an exact 16-bit histogram taken before pass A decides on the device, sub-bucket by sub-bucket:
+//   * a sub-bucket of at most `cap` pairs is sorted inside LDS (cap: 10240 when a pair can be staged
+//     in 6 bytes -- its low 16 key bits and its payload, the rest of the key being the sub-bucket's
+//     -- else 7680);
+//   * a larger one (equal keys, a cluster) is sorted where it lies by two more chained-scan
+//     scatters on the remaining bits, least significant digit first, a -> b -> a inside its own
+//     range, one chain per oversized sub-bucket, after a histogram of just those pairs;
+//   * if more than 256 sub-buckets are oversized, or they hold more than a quarter of the pairs
+//     (four moves of most pairs: no better than the ordinary schedule), every kernel above returns
+//     at once and the plan's four least-significant-digit-first passes run instead; otherwise
+//     those return at once.
+// Both schedules end on the same side (A: a -> b, B: b -> a, local and oversized: in place; four
+// passes: a again).
 #ifndef MRS_HYBRID_HPP
 #define MRS_HYBRID_HPP
 
@@ -28,19 +38,40 @@ constexpr uint32_t kHybSubs = 65536;    // second level, at most: the top 16
 constexpr uint32_t kHybRun = 1;         // HybridHeader::mode: the three-move schedule runs
 constexpr uint32_t kHybFallback = 2;    // the plan's least-significant-digit-first passes run
 constexpr int kHybLocalThreads = 512;   // workgroup of the local sort
-constexpr int kHybLocalKpt = 15;        // pairs per thread at most: sub-buckets of up to 7680 pairs
-constexpr uint32_t kHybLocalCap = kHybLocalThreads * kHybLocalKpt;
+constexpr int kHybLocalKptFull = 15;    // pairs per thread at most when a pair takes 8 bytes of LDS
+#ifndef MRS_LOCAL_KPT_COMPACT
+#define MRS_LOCAL_KPT_COMPACT 20
+#endif
+constexpr int kHybLocalKptCompact = MRS_LOCAL_KPT_COMPACT; // ... when it takes 6
+constexpr uint32_t kHybLocalCapFull = kHybLocalThreads * kHybLocalKptFull;        // 7680
+constexpr uint32_t kHybLocalCapCompact = kHybLocalThreads * kHybLocalKptCompact;  // 10240
 constexpr uint32_t kHybPackedWords = kHybSubs / 2;  // one workgroup's 16-bit counters, two to a word
+constexpr uint32_t kHybMaxBig = 256;    // oversized sub-buckets one call sorts where they lie
 
-// Inside the block that every sort call clears before its first kernel.
+// At the start of the block that every sort call clears before its first kernel.
 struct HybridHeader {
-    uint32_t mode;         // 0 until hybrid_scan_kernel has decided
-    uint32_t num_tiles_b;  // tiles of pass B (0 unless mode == kHybRun)
-    uint32_t overflow;     // a 16-bit counter of the histogram wrapped: counts are not to be trusted
-    uint32_t max_sub;      // largest sub-bucket (diagnostic); 0xFFFFFFFF if the histogram stopped early or wrapped
-    uint32_t pad[60];
+    uint32_t mode;           // 0 until hybrid_scan_kernel has decided
+    uint32_t num_tiles_b;    // tiles of pass B (0 unless mode == kHybRun)
+    uint32_t overflow;       // the histogram cannot be trusted (a key outside the promised window, counts that do not add up)
+    uint32_t max_sub;        // largest sub-bucket (diagnostic)
+    uint32_t num_big;        // oversized sub-buckets (0 unless mode == kHybRun)
+    uint32_t num_tiles_big;  // tiles of the two passes over them
+    uint32_t big_pairs;      // pairs they hold
+    uint32_t high_vary;      // key bits at and above the sorted range differ between keys: no 6-byte staging
+    uint32_t pad[56];
 };
 static_assert(sizeof(HybridHeader) == 256, "the header takes one 256-byte slot of the cleared block");
+
+// Cleared by every sort call together with the header (it follows it in memory).
+struct HybridCleared {
+    HybridHeader hdr;
+    // Counts the histogram workgroups moved out of their 16-bit counters, 32768 at a time, before
+    // those could wrap: the exact count of sub-bucket i is spill[i] + the sum of the fields.
+    uint32_t spill[kHybSubs];
+    // Oversized sub-bucket j: counts of its two local digits, then (hybrid_big_scan_kernel) the
+    // position of each digit's run in the array.
+    uint32_t big_hist[kHybMaxBig][2][256];
+};
 
 // Written in full by the reduce and scan kernels of every call; never cleared.
 struct HybridTables {
@@ -48,6 +79,21 @@ struct HybridTables {
     uint32_t first_tile[kHybBuckets + 4];    // first pass-B tile of bucket b; [256] = tiles in all
     uint32_t sub_start[kHybSubs + 4];        // first element of sub-bucket i; [65536] = n
     uint32_t counts[kHybSubs];               // elements of sub-bucket i
+    uint32_t big_first_tile[kHybMaxBig + 4]; // first tile of oversized sub-bucket j; from [num_big] on: tiles in all
+    uint32_t big_start[kHybMaxBig + 4];      // its first element
+    uint32_t big_end[kHybMaxBig + 4];        // one past its last
+};
+
+// The segments a segmented chained-scan pass runs over (at most 256): segment s holds the
+// elements [start[s], end[s]) and the tiles [first_tile[s], first_tile[s + 1]); the runs of its
+// digits begin at digit_base[s * digit_stride + d].
+struct SegmentTable {
+    const uint32_t* first_tile;
+    const uint32_t* start;
+    const uint32_t* end;
+    const uint32_t* digit_base;
+    uint32_t digit_stride;
+    const uint32_t* num_tiles;  // device word: tiles of the pass
 };
 
 // Device bytes behind the status words of a plan that can run this schedule.
@@ -56,25 +102,37 @@ size_t hybrid_packed_bytes(int grid);
 int hybrid_histogram_grid(int num_cus, uint64_t n);
 int hybrid_local_sort_grid(int num_cus);
 
-// Histogram of the `bits` <= 16 key bits from `shift` up: one packed table per workgroup.
-// windowed: of (key >> shift) - window_base instead, which must be below 2^bits for every key (a
-// key outside that window makes the device refuse the schedule).
+// Exact histogram of the `bits` <= 16 key bits from `shift` up: one packed table per workgroup
+// plus the spill counts in `hc`.  windowed: of (key >> shift) - window_base instead, which must be
+// below 2^bits for every key (a key outside that window makes the device refuse the schedule).
+// `end_bit`: bits at and above it are not sorted on; hc->hdr.high_vary records whether they differ.
 int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t bits, bool windowed, uint32_t window_base,
-                            int grid, uint32_t* packed, HybridHeader* hdr, hipStream_t s);
-// Sum of the `grid` packed tables, its exclusive scan, the tile table of pass B and the decision.
-int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridHeader* hdr, uint32_t n,
-                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, hipStream_t s);
-// One chained-scan pass that runs only if hdr->mode == run_if_mode.  segmented: pass B (tiles and
-// chains per bucket, a.digit_base and a.num_tiles ignored); otherwise a pass over the whole array.
-// persistent: `grid` workgroups draw tiles until none is left (an idle launch then costs `grid`
-// workgroups, not one per tile).
-// windowed: the digits are fields of (key >> a.shift) - a.window_base (PassArgs).
-int hybrid_launch_pass(bool segmented, bool persistent, bool windowed, int threads, int kpt, const PassArgs& a,
-                       const HybridHeader* hdr, const HybridTables* tables, uint32_t run_if_mode, uint32_t grid,
-                       hipStream_t s);
-// Sorts every sub-bucket in place on bits [shift, shift + bits1 + bits2).
+                            uint32_t end_bit, int grid, uint32_t* packed, HybridCleared* hc, hipStream_t s);
+// Sum of the `grid` packed tables and the spill counts, its exclusive scan, the tile tables of
+// pass B and of the passes over oversized sub-buckets, and the decision.  `compact_ok`: the host
+// allows 6-byte staging (the local sort's bits and everything below them fit 16 bits).
+int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridCleared* hc, uint32_t n,
+                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, bool compact_ok, hipStream_t s);
+// One launch of the chained-scan pass for both schedules (either description may be null): `run`
+// is the pass of the three-move schedule (with `seg`: tiles and chains per segment, run->digit_base
+// and run->num_tiles ignored), taken if the device chose that schedule; `other` one of the plan's
+// ordinary passes, taken if it chose those.
+// persistent: `grid` workgroups draw tiles until none is left (a launch with nothing to do then
+// costs `grid` workgroups, not one per tile); a launch with a workgroup per tile serves `run` only.
+// windowed: the digits are fields of (key >> shift) - window_base (PassArgs).
+int hybrid_launch_pass(const PassArgs* run, const SegmentTable* seg, const PassArgs* other, bool persistent, bool windowed,
+                       int threads, int kpt, const HybridHeader* hdr, uint32_t grid, hipStream_t s);
+// Digit counts of the oversized sub-buckets on bits [shift, shift + bits1) and the bits2 above
+// them, and their scan into run positions (two launches).
+int hybrid_launch_big_histogram(const uint32_t* keys, const HybridTables* tables, HybridCleared* hc, uint32_t tile_items,
+                                uint32_t shift, uint32_t bits1, uint32_t bits2, int grid, hipStream_t s);
+// Sorts every sub-bucket that fits a workgroup in place on bits [shift, shift + bits1 + bits2).
+// key_shift: key bits from here up are the same for all keys of a sub-bucket; compact_ok as for
+// hybrid_launch_scan (6-byte staging; the decision kernel has refused the schedule if the bits
+// above the sorted range vary).
 int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,
-                             uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, int grid, hipStream_t s);
+                             uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, uint32_t key_shift,
+                             bool compact_ok, int grid, hipStream_t s);
 
 }  // namespace mrs
 

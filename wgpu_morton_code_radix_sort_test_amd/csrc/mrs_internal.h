@@ -177,7 +177,7 @@ struct mrs_context {
 };
 
 namespace mrs {
-struct HybridHeader;
+struct HybridCleared;
 struct HybridTables;
 }
 
@@ -187,10 +187,11 @@ struct mrs_plan {
     // MRS_ALGO_HYBRID: desc.algo reads MRS_ALGO_ONESWEEP and the plan carries the tables of
     // mrs_hybrid.hpp behind its status words
     bool hybrid;
-    mrs::HybridHeader* hyb_header;  // inside the block cleared per call, before the status words
+    mrs::HybridCleared* hyb_cleared;  // header, spill counts, digit counts of oversized sub-buckets: inside the block cleared per call, before the status words
     mrs::HybridTables* hyb_tables;
     uint32_t* hyb_packed;           // one packed 16-bit histogram per workgroup of the histogram kernel
-    bool hyb_last;                  // the last sort call enqueued both schedules (hyb_header is its record)
+    bool hyb_last;                  // the last sort call enqueued both schedules (hyb_cleared->hdr is its record)
+    bool hyb_compact_ok;            // ... and its local sort could stage a pair in 6 bytes if the device agreed
     uint32_t radix_bits, radix, num_passes;
     uint32_t threads, kpt, tile_items;
     uint64_t max_tiles;
