@@ -125,11 +125,32 @@ def load_modules():
     torch, mrs = _torch, _mrs
 
 
-def make_input(ctx, n, seed):
-    """points -> (keys, idx) on the device; returns the two tensors."""
+def make_input(ctx, n, seed, shape="uniform"):
+    """points -> (keys, idx) on the device; returns the two tensors.  shape: "uniform" (the metric's
+    input: points uniform in the unit cube); "cluster": the same with 5 % of the points inside a cube
+    of 2 % of the side; "surface": half of the points on a sphere shell, the other half on three
+    axis-aligned planes (what the centroids of a triangle mesh look like); "equal": one point."""
     xyz = ctx.generate_points(seed, n)
-    mn = xyz.amin(dim=0).cpu().numpy()
-    mx = xyz.amax(dim=0).cpu().numpy()
+    if shape == "cluster":
+        m = n // 20
+        xyz[:m] = xyz[:m] * 0.02 + 0.4
+    elif shape == "surface":
+        half = n // 2
+        d = xyz[:half] - 0.5
+        d /= d.norm(dim=1, keepdim=True).clamp_min(1e-6)
+        xyz[:half] = 0.5 + 0.45 * d
+        del d
+        third = (n - half) // 3
+        xyz[half:half + third, 0] = 0.3
+        xyz[half + third:half + 2 * third, 1] = 0.55
+        xyz[half + 2 * third:, 2] = 0.8
+    elif shape == "equal":
+        xyz[:] = 0.3
+    if shape == "uniform":
+        mn = xyz.amin(dim=0).cpu().numpy()
+        mx = xyz.amax(dim=0).cpu().numpy()
+    else:
+        mn, mx = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
     keys, idx = ctx.morton_encode30(xyz, mn, mx)
     del xyz
     return keys, idx
@@ -267,7 +288,8 @@ def c4_leg(ctx, log2n=30, sorts=3, context=False):
         "per_pass_ms": [round(float(x), 4) for x in passes],
         "pass_frac_16B": PASS_BYTES_PER_PAIR * n / (float(np.mean(passes)) * 1e-3) / HBM_PEAK_BYTES_PER_S,
         "tile_status_words": "64-bit",
-        "algo": "onesweep: four passes over all 32 key bits (the three-move schedule needs sub-buckets of at most 7680 pairs, n / 65536 here is above that)",
+        "algo": "onesweep: four passes over all 32 key bits (the three-move schedule needs sub-buckets of at most 10240 pairs "
+                "among at most 65536, n / 65536 here is above that)",
         "timing": f"HIP events recorded by the library around every launch of {sorts} sorts after 1 warm-up",
         "verified": bool(ok),
     }
@@ -462,32 +484,40 @@ def main():
             if local > 0:
                 extra["local_sort_frac_16B"] = PASS_BYTES_PER_PAIR * n / local / HBM_PEAK_BYTES_PER_S
             extra["moved_bytes_per_pair"] = 4 + 3 * 16  # what this schedule reads and writes; the 68 above is the metric's figure
-            # the same plan type at the smaller sizes it serves, and on keys the device refuses (the 30-bit
-            # codes declared as 32-bit keys: three quarters of the leading buckets stay empty); library
-            # events, mean of 3 sorts after 1 warm-up; not part of `value`
+            # the same plan type at the other sizes it serves and on other inputs: clustered points (a few
+            # oversized sub-buckets, which two extra segmented passes sort where they lie), points on
+            # surfaces (most sub-buckets oversized: the device takes the four ordinary passes), equal keys,
+            # and 30-bit codes declared as 32-bit keys (three quarters of the leading buckets empty);
+            # library events, mean of 3 sorts after 1 warm-up; not part of `value`
             sweep = {}
-            for label, log2m, eb in (("2^26", 26, 30), ("2^27", 27, 30), ("2^28 refused", 28, 32)):
+            for label, log2m, eb, shape in (("2^26", 26, 30, "uniform"), ("2^27", 27, 30, "uniform"), ("2^29", 29, 30, "uniform"),
+                                            ("2^28 uniform + 5 % cluster", 28, 30, "cluster"),
+                                            ("2^28 surface (sphere shell + three planes)", 28, 30, "surface"),
+                                            ("2^28 all equal", 28, 30, "equal"), ("2^28 refused", 28, 32, "uniform")):
                 m = 1 << log2m
-                if m > n:  # the ping-pong buffers are the headline's
+                if m > n and log2m != 29:  # the ping-pong buffers are the headline's
                     continue
                 p2 = mrs.SortPlan(ctx, m, key_words=1, payload_bytes=4, digit_bits=8, end_bit=eb, algo=mrs.ALGO_HYBRID)
                 p2.set_timing(True)
-                k2, i2 = make_input(ctx, m, SEED + 900 + log2m)
+                k2, i2 = make_input(ctx, m, SEED + 900 + log2m, shape)
+                kb2, vb2 = (kb[:m], vb[:m]) if m <= n else (torch.empty_like(k2), torch.empty_like(i2))
                 pk, pi = k2.clone(), i2.clone()
                 ms2 = []
                 for j in range(4):
                     k2.copy_(pk)
                     i2.copy_(pi)
-                    p2.sort_pairs(k2, i2, kb[:m], vb[:m])
+                    p2.sort_pairs(k2, i2, kb2, vb2)
                     if j:
                         ms2.append(sum(t for _, t in p2.timings()))
                 p2.check()
-                which, _ = p2.schedule()
+                which, biggest = p2.schedule()
+                over_subs, over_pairs, cap = p2.oversized()
                 sweep[label] = {"ms_per_sort": round(float(np.mean(ms2)), 4), "gkeys_per_s": m / (float(np.mean(ms2)) * 1e-3) / 1e9,
                                 "schedule": {0: "passes", 1: "msd", 2: "msd refused by the device"}[which],
-                                "verified": bool(verify_sorted(k2, i2, pk))}
+                                "largest_sub_bucket": biggest, "oversized_sub_buckets": over_subs, "oversized_pairs": over_pairs,
+                                "workgroup_capacity": cap, "verified": bool(verify_sorted(k2, i2, pk))}
                 p2.close()
-                del k2, i2, pk, pi
+                del k2, i2, pk, pi, kb2, vb2
             extra["hybrid_other_inputs"] = sweep
         # Morton encode, reported separately: 12 B read + 8 B written per point
         xyz = ctx.generate_points(SEED, n)

@@ -209,9 +209,10 @@ def test_hybrid_split_of_the_whole_key_space():
             assert bool(s.offered) == (min_n <= n and (n >> s.leading_bits) <= cap * 5 // 6), (begin, end, n)
             if s.offered:
                 assert n / (1 << s.leading_bits) <= cap * 5 // 6 + 1
-                # and no finer split than needed: the next coarser one would exceed about 5000 pairs
+                # and no finer split than needed: the next coarser one would fill a workgroup beyond four fifths
                 if s.leading_bits > max(14, width - 16):
-                    assert n >> (s.leading_bits - 1) > 5120
+                    coarser_cap = 10240 if s.shift + 1 <= 16 else 7680
+                    assert n >> (s.leading_bits - 1) > coarser_cap * 4 // 5
     assert _hybrid_split(lib, 1 << 26, 0, 24)[0] == _lib.MRS_ERR_UNSUPPORTED
     assert _hybrid_split(lib, 1 << 30, 0, 30)[0] == _lib.MRS_ERR_UNSUPPORTED
     assert _hybrid_split(lib, 0, 0, 30)[0] == _lib.MRS_ERR_UNSUPPORTED
@@ -245,8 +246,10 @@ def test_hybrid_split_of_a_window():
         assert s.base == lo >> s.shift
         subs = (hi >> s.shift) - s.base + 1
         assert subs <= 1 << s.leading_bits
-        # about 5000 pairs per sub-bucket, or with the finest split what a workgroup holds less a sixth
-        assert n // subs <= (5120 if s.leading_bits < 16 else (10240 if s.shift <= 16 else 7680) * 5 // 6)
+        # four fifths of what a workgroup holds (10240 pairs staged in 6 bytes each when the sub-bucket's
+        # own bits start at bit 16 or below, else 7680), or with the finest split all but a sixth of it
+        cap = 10240 if s.shift <= 16 else 7680
+        assert n // subs <= (cap * 4 // 5 if s.leading_bits < 16 else cap * 5 // 6)
     assert offered > 2000
     # a window so narrow that its keys cannot spread is not offered; nor is one too wide for n
     assert not _hybrid_split(lib, 1 << 27, 0, 32, (12345, 12345))[1].offered

@@ -923,7 +923,7 @@ static uint64_t hybrid_min_n(uint32_t width, const TestAids& aids)
 static uint32_t hybrid_local_cap(uint32_t shift) { return shift <= 16u ? kHybLocalCapCompact : kHybLocalCapFull; }
 
 // Key bits passes A and B take together: the coarsest split whose sub-buckets hold at most four
-// fifths of a workgroup's capacity on evenly spread keys (8192 of 10240 pairs, 5120 of 7680: every
+// fifths of a workgroup's capacity on evenly spread keys (8192 of 10240 pairs, 6144 of 7680: every
 // visit of a sub-bucket costs the local sort about 4 microseconds whatever its size, so fewer,
 // fuller sub-buckets are faster -- 2^28 pairs: 0.95 ms with 2^15 sub-buckets, 1.19 ms with 2^16 --
 // and the fifth left free takes uneven keys), at least 14, and at least so many that 16 bits or
@@ -931,8 +931,7 @@ static uint32_t hybrid_local_cap(uint32_t shift) { return shift <= 16u ? kHybLoc
 static uint32_t hybrid_msd_bits(uint32_t end, uint32_t width, uint32_t n, const TestAids& aids)
 {
     uint32_t bits = 14;
-    while (bits < 16 && (static_cast<uint64_t>(n) >> bits) > (hybrid_local_cap(end - bits) == kHybLocalCapCompact ? 8192u : 5120u))
-        ++bits;
+    while (bits < 16 && (static_cast<uint64_t>(n) >> bits) > hybrid_local_cap(end - bits) * 4u / 5u) ++bits;
     // test aid: the finer splits on inputs a checker can follow
     if (aids.hybrid_leading_bits >= 14 && aids.hybrid_leading_bits <= 16) bits = aids.hybrid_leading_bits;
     if (bits + 16 < width) bits = width - 16;
@@ -961,7 +960,7 @@ static bool hybrid_window_split(uint32_t begin, uint32_t n, uint64_t lo, uint64_
         uint32_t shift = begin + 2;  // the local sort takes two digits of at least one bit
         while (shift < 32 && ((hi >> shift) - (lo >> shift)) >= (1ull << bits)) ++shift;
         const uint64_t subs = (hi >> shift) - (lo >> shift) + 1;
-        const uint64_t limit = bits < 16 ? (hybrid_local_cap(shift) == kHybLocalCapCompact ? 8192u : 5120u) : hybrid_local_cap(shift) * 5ull / 6;
+        const uint64_t limit = bits < 16 ? hybrid_local_cap(shift) * 4ull / 5 : hybrid_local_cap(shift) * 5ull / 6;
         if (shift - begin <= 16 && n / subs <= limit) {
             *out = HybridSplit{bits, shift, static_cast<uint32_t>(lo >> shift), true};
             return true;
@@ -1017,30 +1016,20 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     plan->hyb_compact_ok = compact_ok;
     HybridCleared* hc = plan->hyb_cleared;
     const HybridHeader* hdr = &hc->hdr;
+    // the same read of the keys counts the two lowest digits of the plan's ordinary passes
     if (int rc = hybrid_launch_histogram(static_cast<const uint32_t*>(keys_a), n32, split.shift, msd_bits, split.windowed,
-                                         split.base, end_bit, hist_grid, plan->hyb_packed, hc, s))
+                                         split.base, begin_bit, end_bit, hist_grid, plan->hyb_packed, hc, plan->control->ghist, s))
         return rc;
     if (int rc = mark(plan, "msd_histogram", s)) return rc;
     // test aid: the device takes the plan's ordinary passes whatever the keys are
     const uint32_t force = plan->aids.hybrid_force_fallback ? kHybFallback : 0u;
+    // ... and a decision against the schedule leaves the digit prefix sums of all four ordinary passes
+    // behind (the upper two digits are sums over the exact table): no second read of the keys
     if (int rc = hybrid_launch_scan(plan->hyb_packed, hist_grid, plan->hyb_tables, hc, n32, plan->tile_items, force, bits_b,
-                                    compact_ok, s))
+                                    compact_ok, plan->control->ghist, begin_bit, end_bit, split.shift, split.windowed ? split.base : 0u,
+                                    s))
         return rc;
     if (int rc = mark(plan, "msd_scan", s)) return rc;
-    // the other schedule's digit histograms: counted only if the device chose it
-    GlobalHistArgs h{};
-    h.keys = keys_a;
-    h.n = n32;
-    h.begin_bit = begin_bit;
-    h.end_bit = end_bit;
-    h.num_passes = plan->num_passes;
-    h.ghist = plan->control->ghist;
-    h.gate = &hc->hdr.mode;
-    h.gate_value = kHybFallback;
-    if (int rc = launch_global_hist(plan, h, s)) return rc;
-    if (int rc = mark(plan, "fallback_histogram", s)) return rc;
-    if (int rc = launch_ghist_scan(plan, plan->num_passes, 0, s)) return rc;
-    if (int rc = mark(plan, "histogram_scan", s)) return rc;
 
     // Passes loop over tiles with one workgroup per compute unit where that costs nothing (same time
     // per pass within 1 %): a launch with nothing to do is then 256 workgroups instead of 8448 (0.005

@@ -5,6 +5,21 @@
 
 namespace mrs {
 
+// Inclusive prefix sum over the 64 lanes of a wave whose lanes are all active: inside rows of 16
+// lanes by DPP row shifts (a lane without a source lane adds 0), then the totals of the rows
+// before it (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six dependent adds,
+// against six round trips through the LDS crossbar for the same scan by __shfl_up.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
+{
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xA, 0xF, false);  // row_bcast:15
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xC, 0xF, false);  // row_bcast:31
+    return x;
+}
+
 // ---- exact 16-bit histogram -----------------------------------------------------------------
 // One LDS atomic per key into 65536 counters of 16 bits, two to a word (128 KiB: one workgroup
 // of 1024 threads per compute unit), 16-byte nontemporal loads, four in flight per thread.  A
@@ -20,13 +35,23 @@ namespace mrs {
 // otherwise queue 64 lanes on one word: 0.9 ms instead of 0.17 at 2^28 equal keys).  As a last
 // check a workgroup whose fields and spills do not add up to the keys it read raises
 // hdr->overflow, and the decision kernel then chooses the other schedule.
+//
+// The same read of the keys also counts the two lowest digits of the plan's ordinary passes (bits
+// [begin_bit, begin_bit + 8) and the 8 above), into 8 interleaved copies of 256 counters each
+// (copy = lane % 8: the lanes of one instruction spread over the LDS banks whatever their digits
+// are), added to `low_hist` at the end.  Together with the exact table (which holds the digits
+// above those 16 bits: the local sort takes at most 16) that is every histogram the ordinary
+// passes need, so a call the device refuses does not read the keys a second time.
+constexpr int kLowCopies = 8;
 __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                  uint32_t vectors, uint32_t shift, uint32_t bits,
                                                                  uint32_t* __restrict__ packed, HybridCleared* hc,
-                                                                 uint32_t window_base, uint32_t windowed, uint32_t end_bit)
+                                                                 uint32_t window_base, uint32_t windowed, uint32_t end_bit,
+                                                                 uint32_t begin_bit, uint32_t* __restrict__ low_hist)
 {
     constexpr int THREADS = 1024, UNROLL = 4;
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kHybPackedWords];
+    __shared__ uint32_t s_low[2][256 * kLowCopies];
     __shared__ int s_diff;
     __shared__ uint32_t s_flags;  // bit 0: a key outside the window, bit 1: bits at or above end_bit differ
     const uint32_t tid = threadIdx.x;
@@ -34,11 +59,18 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
         uint4* z = reinterpret_cast<uint4*>(s_cnt);
         for (uint32_t j = tid; j < kHybPackedWords / 4; j += THREADS) z[j] = make_uint4(0, 0, 0, 0);
     }
+    for (uint32_t j = tid; j < 2 * 256 * kLowCopies; j += THREADS) (&s_low[0][0])[j] = 0;
     if (tid == 0) {
         s_diff = 0;
         s_flags = 0;
     }
     __syncthreads();
+    const uint32_t low_copy = tid & (kLowCopies - 1);
+    // the two lowest digits of the ordinary passes; no result is needed, so no returning atomic
+    auto count_low = [&](uint32_t k, uint32_t amount) __attribute__((always_inline)) {
+        atomicAdd(&s_low[0][__builtin_amdgcn_ubfe(k, begin_bit, 8) * kLowCopies + low_copy], amount);
+        atomicAdd(&s_low[1][__builtin_amdgcn_ubfe(k, begin_bit + 8u, 8) * kLowCopies + low_copy], amount);
+    };
     uint32_t mine = 0;     // keys this lane read
     uint32_t spilled = 0;  // times this lane moved 32768 counts out of a field
     uint32_t differ = 0;   // bits in which a key of this lane differs from the first key of the array
@@ -71,6 +103,7 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
     };
     // evenly spread keys: one add per key and nothing else
     auto count_plain = [&](uint32_t k) __attribute__((always_inline)) {
+        count_low(k, 1u);
         const uint32_t b = sub_bucket(k);
         const uint32_t half = (b & 1u) * 16u;
         const uint32_t old = atomicAdd(&s_cnt[b >> 1], 1u << half);
@@ -84,6 +117,19 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
     };
     // keys that crowd on few sub-buckets: the lanes that hold the first lane's sub-bucket share one add
     auto count_grouped = [&](uint32_t k) __attribute__((always_inline)) {
+        {
+            // equal keys share their low digits too: one lane counts for the lanes that hold the
+            // first lane's 16 low bits
+            const uint32_t low = __builtin_amdgcn_ubfe(k, begin_bit, 16);
+            const uint32_t low0 = __builtin_amdgcn_readfirstlane(low);
+            const unsigned long long same_low = __builtin_amdgcn_uicmp(low, low0, 32 /* == */);
+            const uint32_t group_low = static_cast<uint32_t>(__popcll(same_low));
+            if (group_low >= 8u && low == low0) {
+                if (lanes_below(static_cast<uint32_t>(same_low), static_cast<uint32_t>(same_low >> 32)) == 0u) count_low(k, group_low);
+            } else {
+                count_low(k, 1u);
+            }
+        }
         const uint32_t b = sub_bucket(k);
         const uint32_t b0 = __builtin_amdgcn_readfirstlane(b);
         const unsigned long long same = __builtin_amdgcn_uicmp(b, b0, 32 /* == */);  // among the active lanes
@@ -151,6 +197,13 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
                       (w.w & 0xFFFFu) + (w.w >> 16);
         }
     }
+    // the low digits: the copies added up, one global add per counter that is not zero
+    for (uint32_t j = tid; j < 2 * 256; j += THREADS) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int cc = 0; cc < kLowCopies; ++cc) sum += (&s_low[0][0])[j * kLowCopies + cc];
+        if (sum) atomicAdd(&low_hist[j], sum);
+    }
     int diff = static_cast<int>(mine) - static_cast<int>(fields) - static_cast<int>(spilled * 0x8000u);
     uint32_t flags = outside | ((end_bit < 32u && (differ >> end_bit) != 0u) ? 2u : 0u);
 #pragma unroll
@@ -214,9 +267,21 @@ __global__ __launch_bounds__(256) void hybrid_reduce_kernel(const uint32_t* __re
 // has 2^sub_bits >= 64 sub-buckets, so it starts with a thread), bucket starts, the tile table of
 // pass B, the list of oversized sub-buckets with their tile table, and the decision.  Buckets and
 // sub-buckets the split does not use are empty and start at n.
+// If the decision is against the schedule, the digit histograms of the plan's four ordinary passes
+// are finished here: `ghist` holds the counts of the two lowest digits (the histogram kernel's), the
+// two above them are sums over the exact table (digit p of the keys of sub-bucket i is a bit field
+// of i + window_base, because the table starts at or below bit begin_bit + 16), and all four are
+// turned into exclusive prefix sums, which is what the passes read.
+struct OrdinaryDigits {
+    uint32_t* ghist;        // [4][256]: counts of passes 0 and 1 on entry
+    uint32_t shift2, mask2; // digit of pass 2 = ((i + window_base) >> shift2) & mask2
+    uint32_t shift3, mask3;
+    uint32_t window_base;
+};
+
 __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, HybridCleared* hc, uint32_t n,
                                                             uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits,
-                                                            uint32_t compact_ok)
+                                                            uint32_t compact_ok, const OrdinaryDigits od)
 {
     __shared__ uint32_t s_wsum[16];
     __shared__ uint32_t s_bigw[16];
@@ -224,7 +289,9 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
     __shared__ uint32_t s_tsum[4];
     __shared__ uint32_t s_bigtsum[4];
     __shared__ uint32_t s_bigcnt[kHybMaxBig];
-    __shared__ uint32_t s_max, s_bigpairs;
+    __shared__ uint32_t s_high[2][256];
+    __shared__ uint32_t s_psum[16];
+    __shared__ uint32_t s_max, s_bigpairs, s_mode;
     HybridHeader* hdr = &hc->hdr;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // what a workgroup of the local sort can hold
@@ -371,7 +438,50 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
             hdr->big_pairs = s_bigpairs;
             hdr->max_sub = s_max;
             hdr->mode = ok ? kHybRun : kHybFallback;
+            s_mode = ok ? kHybRun : kHybFallback;
         }
+    }
+    if (tid < 512) (&s_high[0][0])[tid] = 0;
+    __syncthreads();
+    if (s_mode == kHybRun) return;  // uniform
+    // ---- the ordinary passes run: their digit histograms ----
+    if (sum != 0u) {
+        // consecutive sub-buckets share their digits in runs (one run per thread for pass 3 unless a
+        // window base shifts the thread's 64 sub-buckets across a boundary): one add per run
+        const uint32_t first = tid * 64u + od.window_base;
+        uint32_t run2 = (first >> od.shift2) & od.mask2, sum2 = 0;
+        uint32_t run3 = (first >> od.shift3) & od.mask3, sum3 = 0;
+#pragma unroll 1
+        for (int q = 0; q < 64; ++q) {
+            const uint32_t at = first + static_cast<uint32_t>(q);
+            const uint32_t d2 = (at >> od.shift2) & od.mask2, d3 = (at >> od.shift3) & od.mask3;
+            if (d2 != run2) {
+                if (sum2) atomicAdd(&s_high[0][run2], sum2);
+                run2 = d2;
+                sum2 = 0;
+            }
+            if (d3 != run3) {
+                if (sum3) atomicAdd(&s_high[1][run3], sum3);
+                run3 = d3;
+                sum3 = 0;
+            }
+            sum2 += c[q];
+            sum3 += c[q];
+        }
+        if (sum2) atomicAdd(&s_high[0][run2], sum2);
+        if (sum3) atomicAdd(&s_high[1][run3], sum3);
+    }
+    __syncthreads();
+    {
+        // thread t: digit t & 255 of pass t >> 8; four waves per pass
+        const uint32_t pass = tid >> 8, digit = tid & 255u;
+        const uint32_t own = pass < 2 ? od.ghist[tid] : s_high[pass - 2][digit];
+        const uint32_t inc = wave_inclusive_sum(own);
+        if (lane == 63) s_psum[wave] = inc;
+        __syncthreads();
+        uint32_t off = inc - own;
+        for (uint32_t w = pass * 4u; w < wave; ++w) off += s_psum[w];
+        od.ghist[tid] = off;
     }
 }
 
@@ -580,21 +690,6 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
 // key of the sub-bucket (key_shift <= 16, and the histogram kernel found no differing bits above
 // the sorted range: the decision kernel refuses the schedule otherwise) and is put back at the
 // write-out.
-// Inclusive prefix sum over the 64 lanes of a wave whose lanes are all active: inside rows of 16
-// lanes by DPP row shifts (a lane without a source lane adds 0), then the totals of the rows
-// before it (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six dependent adds,
-// against six round trips through the LDS crossbar for the same scan by __shfl_up.
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
-{
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xF, 0xF, false);  // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xF, 0xF, false);  // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xF, 0xF, false);  // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xF, 0xF, false);  // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xA, 0xF, false);  // row_bcast:15
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xC, 0xF, false);  // row_bcast:31
-    return x;
-}
-
 constexpr uint32_t kLocalMinGrid = 256;  // so that a workgroup has at most this many sub-buckets
 constexpr uint32_t kLocalMaxPerGroup = kHybSubs / kLocalMinGrid;
 constexpr int kLocalStageBytes = kHybLocalThreads * kHybLocalKptFull * 8;
@@ -806,25 +901,37 @@ int hybrid_local_sort_grid(int num_cus)
 }
 
 int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t bits, bool windowed, uint32_t window_base,
-                            uint32_t end_bit, int grid, uint32_t* packed, HybridCleared* hc, hipStream_t s)
+                            uint32_t begin_bit, uint32_t end_bit, int grid, uint32_t* packed, HybridCleared* hc,
+                            uint32_t* low_hist, hipStream_t s)
 {
+    if (shift > begin_bit + 16u) return fail(MRS_ERR_UNSUPPORTED, "the exact table must start within 16 bits of begin_bit");
     const ProfilerRange range("Histogram calculation");  // src/main.rs:597
     const uint32_t vectors = (reinterpret_cast<uintptr_t>(keys) & 15u) ? 0u : n / 4u;
     hipLaunchKernelGGL(hybrid_histogram_kernel, dim3(grid), dim3(1024), 0, s, keys, n, vectors, shift, bits, packed, hc,
-                       window_base, windowed ? 1u : 0u, end_bit);
+                       window_base, windowed ? 1u : 0u, end_bit, begin_bit, low_hist);
     MRS_CHECK_LAUNCH("hybrid_histogram_kernel");
     return MRS_OK;
 }
 
 int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridCleared* hc, uint32_t n,
-                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, bool compact_ok, hipStream_t s)
+                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, bool compact_ok, uint32_t* ghist,
+                       uint32_t begin_bit, uint32_t end_bit, uint32_t shift, uint32_t window_base, hipStream_t s)
 {
     if (sub_bits < 6 || sub_bits > 8) return fail(MRS_ERR_UNSUPPORTED, "a bucket has 64 to 256 sub-buckets");
+    if (shift > begin_bit + 16u || end_bit <= begin_bit + 24u || end_bit > begin_bit + 32u)
+        return fail(MRS_ERR_UNSUPPORTED, "the ordinary passes are four digits of 8 bits, the exact table starts within the lowest two");
+    OrdinaryDigits od{};
+    od.ghist = ghist;
+    od.shift2 = begin_bit + 16u - shift;
+    od.mask2 = 255u;
+    od.shift3 = begin_bit + 24u - shift;
+    od.mask3 = (1u << (end_bit - begin_bit - 24u)) - 1u;
+    od.window_base = window_base;
     const ProfilerRange range("Small Prefix Sum");  // src/main.rs:625
     hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(kHybPackedWords / 64), dim3(256), 0, s, packed, grid, hc->spill, tables->counts);
     MRS_CHECK_LAUNCH("hybrid_reduce_kernel");
     hipLaunchKernelGGL(hybrid_scan_kernel, dim3(1), dim3(1024), 0, s, tables, hc, n, tile_items, force_mode, sub_bits,
-                       compact_ok ? 1u : 0u);
+                       compact_ok ? 1u : 0u, od);
     MRS_CHECK_LAUNCH("hybrid_scan_kernel");
     return MRS_OK;
 }

@@ -106,13 +106,21 @@ int hybrid_local_sort_grid(int num_cus);
 // plus the spill counts in `hc`.  windowed: of (key >> shift) - window_base instead, which must be
 // below 2^bits for every key (a key outside that window makes the device refuse the schedule).
 // `end_bit`: bits at and above it are not sorted on; hc->hdr.high_vary records whether they differ.
+// low_hist (u32[2][256], zeroed): receives the counts of the digits [begin_bit, begin_bit + 8) and
+// [begin_bit + 8, begin_bit + 16) of every key, the two lowest digits of the plan's ordinary passes.
 int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t bits, bool windowed, uint32_t window_base,
-                            uint32_t end_bit, int grid, uint32_t* packed, HybridCleared* hc, hipStream_t s);
+                            uint32_t begin_bit, uint32_t end_bit, int grid, uint32_t* packed, HybridCleared* hc,
+                            uint32_t* low_hist, hipStream_t s);
 // Sum of the `grid` packed tables and the spill counts, its exclusive scan, the tile tables of
 // pass B and of the passes over oversized sub-buckets, and the decision.  `compact_ok`: the host
-// allows 6-byte staging (the local sort's bits and everything below them fit 16 bits).
+// allows 6-byte staging (the local sort's bits and everything below them fit 16 bits).  If the
+// decision is against the schedule, ghist (u32[4][256]; [0] and [1] as hybrid_launch_histogram left
+// them) receives the exclusive digit prefix sums of the plan's four ordinary passes over
+// [begin_bit, end_bit): the two upper digits are sums over the exact table, which starts at `shift`
+// (within 16 bits of begin_bit) and, windowed, at sub-bucket `window_base`.
 int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridCleared* hc, uint32_t n,
-                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, bool compact_ok, hipStream_t s);
+                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, bool compact_ok, uint32_t* ghist,
+                       uint32_t begin_bit, uint32_t end_bit, uint32_t shift, uint32_t window_base, hipStream_t s);
 // One launch of the chained-scan pass for both schedules (either description may be null): `run`
 // is the pass of the three-move schedule (with `seg`: tiles and chains per segment, run->digit_base
 // and run->num_tiles ignored), taken if the device chose that schedule; `other` one of the plan's
