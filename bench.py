@@ -71,6 +71,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-log2", type=int, default=0, help="pairs of the parallel CPU sort = 2^this (0 = the whole step input)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the 2^30-pair leg")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed steps and the roofline's three event-timed sorts: no other sizes or inputs, no "
+                         "encode pipelines, no CPU baseline, no context number, no 2^30 / 2^31 legs (for profiler runs, so "
+                         "that every launch in a kernel summary is a launch of the headline size)")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="every rank prints its RANK / WORLD_SIZE / pairs per GPU as one JSON line and exits "
                          "without touching the GPU or the library (checks the rank launcher)")
@@ -490,7 +494,7 @@ def main():
             # and 30-bit codes declared as 32-bit keys (three quarters of the leading buckets empty);
             # library events, mean of 3 sorts after 1 warm-up; not part of `value`
             sweep = {}
-            for label, log2m, eb, shape in (("2^26", 26, 30, "uniform"), ("2^27", 27, 30, "uniform"), ("2^29", 29, 30, "uniform"),
+            for label, log2m, eb, shape in () if args.no_extras else (("2^26", 26, 30, "uniform"), ("2^27", 27, 30, "uniform"), ("2^29", 29, 30, "uniform"),
                                             ("2^28 uniform + 5 % cluster", 28, 30, "cluster"),
                                             ("2^28 surface (sphere shell + three planes)", 28, 30, "surface"),
                                             ("2^28 all equal", 28, 30, "equal"), ("2^28 refused", 28, 32, "uniform")):
@@ -519,46 +523,47 @@ def main():
                 p2.close()
                 del k2, i2, pk, pi, kb2, vb2
             extra["hybrid_other_inputs"] = sweep
-        # Morton encode, reported separately: 12 B read + 8 B written per point
-        xyz = ctx.generate_points(SEED, n)
-        mn, mx = xyz.amin(dim=0).cpu().numpy(), xyz.amax(dim=0).cpu().numpy()
-        ek, ei = ctx.morton_encode30(xyz, mn, mx)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            ctx.morton_encode30(xyz, mn, mx, ek, ei)
-        e1.record()
-        torch.cuda.synchronize()
-        enc_ms = e0.elapsed_time(e1) / 5
-        extra["morton_encode30_ms"] = round(enc_ms, 4)
-        extra["morton_encode30_GBps"] = 20.0 * n / (enc_ms * 1e-3) / 1e9
-        # encode + sort as one pipeline, with the encoder that leaves the digit histograms in the
-        # plan (the sort then skips its own read of the keys) and without; not part of `value`
-        # ... and with no index array at all: the encoder writes keys only (12 + 4 B per point) and the
-        # sort makes the indices up in its first pass (mrs_sort_pairs_indexed, 64 B per pair)
-        for label, primed in (("encode_then_sort_ms", False), ("encode_for_sort_then_sort_ms", True),
-                              ("encode_keys_then_sort_indexed_ms", None)):
-            times = []
-            for _ in range(4):
-                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                p0.record()
-                if primed is None:
-                    ctx.morton_encode30(xyz, mn, mx, ek, keys_only=True)
-                    plan.sort_pairs_indexed(ek, ei, kb, vb)
-                elif primed:
-                    plan.morton_encode30_for_sort(xyz, mn, mx, ek, ei)
-                    plan.sort_pairs_primed(ek, ei, kb, vb)
-                else:
-                    ctx.morton_encode30(xyz, mn, mx, ek, ei)
-                    plan.sort_pairs(ek, ei, kb, vb)
-                p1.record()
-                torch.cuda.synchronize()
-                times.append(p0.elapsed_time(p1))
-            extra[label] = round(float(np.median(times[1:])), 4)
-        del xyz, ek, ei
+        if not args.no_extras:
+            # Morton encode, reported separately: 12 B read + 8 B written per point
+            xyz = ctx.generate_points(SEED, n)
+            mn, mx = xyz.amin(dim=0).cpu().numpy(), xyz.amax(dim=0).cpu().numpy()
+            ek, ei = ctx.morton_encode30(xyz, mn, mx)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ctx.morton_encode30(xyz, mn, mx, ek, ei)
+            e1.record()
+            torch.cuda.synchronize()
+            enc_ms = e0.elapsed_time(e1) / 5
+            extra["morton_encode30_ms"] = round(enc_ms, 4)
+            extra["morton_encode30_GBps"] = 20.0 * n / (enc_ms * 1e-3) / 1e9
+            # encode + sort as one pipeline, with the encoder that leaves the digit histograms in the
+            # plan (the sort then skips its own read of the keys) and without; not part of `value`
+            # ... and with no index array at all: the encoder writes keys only (12 + 4 B per point) and the
+            # sort makes the indices up in its first pass (mrs_sort_pairs_indexed, 64 B per pair)
+            for label, primed in (("encode_then_sort_ms", False), ("encode_for_sort_then_sort_ms", True),
+                                  ("encode_keys_then_sort_indexed_ms", None)):
+                times = []
+                for _ in range(4):
+                    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    p0.record()
+                    if primed is None:
+                        ctx.morton_encode30(xyz, mn, mx, ek, keys_only=True)
+                        plan.sort_pairs_indexed(ek, ei, kb, vb)
+                    elif primed:
+                        plan.morton_encode30_for_sort(xyz, mn, mx, ek, ei)
+                        plan.sort_pairs_primed(ek, ei, kb, vb)
+                    else:
+                        ctx.morton_encode30(xyz, mn, mx, ek, ei)
+                        plan.sort_pairs(ek, ei, kb, vb)
+                    p1.record()
+                    torch.cuda.synchronize()
+                    times.append(p0.elapsed_time(p1))
+                extra[label] = round(float(np.median(times[1:])), 4)
+            del xyz, ek, ei
 
     context = None
-    if not distributed and rank == 0 and algo in (mrs.ALGO_ONESWEEP, mrs.ALGO_HYBRID):
+    if not distributed and rank == 0 and algo in (mrs.ALGO_ONESWEEP, mrs.ALGO_HYBRID) and not args.no_extras:
         # same-box context (never a target): the vendor's radix sort on one of the step inputs
         try:
             k_in, i_in = make_input(ctx, n, SEED + 777)
@@ -601,7 +606,7 @@ def main():
             dist.barrier()
 
     cpu = None
-    if rank == 0 and not distributed and not args.no_cpu_baseline:
+    if rank == 0 and not distributed and not args.no_cpu_baseline and not args.no_extras:
         m = n if args.cpu_sample_log2 == 0 else min(n, 1 << args.cpu_sample_log2)
         sk, si = make_input(ctx, n, SEED + ((total_steps - 1) % pool)) if not (restore and total_steps > pool) \
             else pristine[0]
@@ -612,7 +617,7 @@ def main():
 
     c4 = None
     c5_one_gpu = None
-    if rank == 0 and not distributed and not args.no_c4 and algo in (mrs.ALGO_ONESWEEP, mrs.ALGO_HYBRID) and n == (1 << 28):
+    if rank == 0 and not distributed and not args.no_c4 and not args.no_extras and algo in (mrs.ALGO_ONESWEEP, mrs.ALGO_HYBRID) and n == (1 << 28):
         # free the pool first: the 2^30 leg wants about 45 GiB
         del inputs, kb, vb, out
         if restore:

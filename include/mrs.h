@@ -301,7 +301,10 @@ int mrs_scatter(mrs_plan* plan, uint64_t n, const void* keys_in, const void* val
  * MRS_ALGO_ONESWEEP plan for 32-bit keys), so that mrs_sort_pairs_primed(plan, n, keys_dev, ...)
  * can skip its own read of the keys (the histogram launch before the passes, src/main.rs:594-603
  * being the reference's per-pass counterpart).  The plan's memory is used, so the call must be
- * ordered before the sort on one stream.  Any other call that takes the plan drops the histograms. */
+ * ordered before the sort on one stream.  Any other call that takes the plan drops the histograms.
+ * On an MRS_ALGO_HYBRID plan and an n that takes the three-move schedule the call is
+ * mrs_morton_encode30: that schedule's own single read of the keys counts everything both of its
+ * pass sequences need, and histograms left here would only cost the encoder time. */
 int mrs_morton_encode30_for_sort(mrs_plan* plan, const float* xyz_dev, uint64_t n, const float* mn,
                                  const float* mx, uint32_t* keys_dev, uint32_t* idx_dev, void* stream);
 /* mrs_sort_pairs that consumes the histograms mrs_morton_encode30_for_sort left in the plan.

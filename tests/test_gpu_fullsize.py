@@ -113,6 +113,73 @@ def test_full_size_hybrid_plan_equals_four_passes(ctx, mrs, log2n, end_bit, want
     plan.close()
 
 
+def _shaped_keys(ctx, n, shape, seed):
+    """30-bit codes at sizes the CPU checker is too slow for.  "hot20": a fifth of the keys share their
+    16 leading bits (one sub-bucket far beyond any 16-bit counter of the histogram); "cluster": 5 % of
+    the points in a small cube; "surface": points on a sphere shell and on three planes."""
+    xyz = ctx.generate_points(seed, n)
+    if shape == "cluster":
+        m = n // 20
+        xyz[:m] = xyz[:m] * 0.02 + 0.4
+    elif shape == "surface":
+        half = n // 2
+        d = xyz[:half] - 0.5
+        d /= d.norm(dim=1, keepdim=True).clamp_min(1e-6)
+        xyz[:half] = 0.5 + 0.45 * d
+        third = (n - half) // 3
+        xyz[half:half + third, 0] = 0.3
+        xyz[half + third:half + 2 * third, 1] = 0.55
+        xyz[half + 2 * third:, 2] = 0.8
+    keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+    del xyz
+    if shape == "hot20":
+        m = n // 5
+        keys[:m] = (keys[:m] & 0x3FFF) | (0x2BCD << 14)
+        perm = torch.randperm(n, device=keys.device)
+        keys = keys[perm].contiguous()
+    return keys, idx
+
+
+@pytest.mark.parametrize("log2n,shape,want", [(26, "hot20", "msd"), (28, "cluster", "msd"), (27, "surface", "refused"),
+                                              (29, "cluster", "msd")])
+def test_full_size_uneven_keys(ctx, mrs, log2n, shape, want):
+    """Inputs whose sub-buckets are far from even, at sizes only the GPU can check: the result must be
+    the four-pass plan's, pair for pair, whatever the device decides.  A sub-bucket with a fifth of
+    2^26 keys overflows the 16-bit counters of every histogram workgroup many times over (the
+    counts must still be exact) and is sorted by the two extra passes; clustered points leave a
+    handful of oversized sub-buckets; points on surfaces leave thousands, and the device takes the
+    ordinary passes with the histograms it already has."""
+    n = 1 << log2n
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 60 * n:
+        pytest.skip("not enough device memory for this size")
+    keys, idx = _shaped_keys(ctx, n, shape, 31 + log2n)
+    keys_in = keys.clone()
+    kb, vb = torch.empty_like(keys), torch.empty_like(idx)
+    ref = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, end_bit=30, algo=mrs.ALGO_ONESWEEP)
+    rk, rv = keys.clone(), idx.clone()
+    assert not ref.sort_pairs(rk, rv, kb, vb)
+    ref.check()
+    ref.close()
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, end_bit=30, algo=mrs.ALGO_HYBRID)
+    for again in range(2):  # the second call runs on the tables the first one left
+        keys.copy_(keys_in)
+        idx.copy_(torch.arange(n, dtype=torch.int32, device=ctx.device))
+        assert not plan.sort_pairs(keys, idx, kb, vb)
+        plan.check()
+        schedule, largest = plan.schedule()
+        subs, pairs, cap = plan.oversized()
+        assert schedule == (plan.SCHEDULE_MSD if want == "msd" else plan.SCHEDULE_MSD_REFUSED), (largest, subs, pairs)
+        if want == "msd":
+            assert 1 <= subs <= 256 and cap < pairs <= n // 4 and largest > cap, (largest, subs, pairs, cap)
+            if shape == "hot20":
+                assert subs == 1 and largest >= n // 5
+        assert bool((keys == rk).all()), "keys differ from the four-pass plan's"
+        assert bool((idx == rv).all()), "payload differs from the four-pass plan's"
+    check_sorted_pairs(keys, idx, keys_in)
+    plan.close()
+
+
 @pytest.mark.parametrize("payload_words", [1, 4])
 def test_large_u64_keys_properties(ctx, mrs, payload_words):
     """64-bit keys (the reference's code type) with an index or a 16-byte TriangleIndices-sized

@@ -440,9 +440,13 @@ def test_primed_call_on_a_hybrid_plan(ctx, oracle, mrs, small_inputs_take_the_sc
     keys, idx = plan.morton_encode30_for_sort(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
     hk, hv = to_u32(keys).copy(), to_u32(idx).copy()
     kb, vb = torch.empty_like(keys), torch.empty_like(idx)
+    plan.set_timing(True)
     assert not plan.sort_pairs_primed(keys, idx, kb, vb)
     plan.check()
     assert plan.schedule()[0] == plan.SCHEDULE_MSD
+    # one read of the keys before the passes, the schedule's own; nothing else counts digits
+    labels = [lab for lab, _ in plan.timings()]
+    assert labels.count("msd_histogram") == 1 and not any("global_histogram" in lab or lab == "fallback_histogram" for lab in labels), labels
     rk, rv = oracle.stable_sort_pairs(hk, hv, n, 1, 1, 0, 30)
     assert np.array_equal(to_u32(keys), rk) and np.array_equal(to_u32(idx), rv)
     plan.close()

@@ -59,8 +59,9 @@ def summarize_hybrid(args, n, library_rows):
         return {"read_bytes_per_launch": f * 1024.0 * factor, "write_bytes_per_launch": w * 1024.0 * cal_w,
                 "bytes_per_launch": f * 1024.0 * factor + w * 1024.0 * cal_w, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w}
 
-    a = traffic("hybrid_pass_kernel<false, false")
-    b = traffic("hybrid_pass_kernel<true, true") if pick(fetch, "hybrid_pass_kernel<true, true") else traffic("hybrid_pass_kernel<true, false")
+    # the last template argument of hybrid_pass_kernel names the launch: 0 pass A, 1 pass B
+    a = traffic("32, 0>(")
+    b = traffic("32, 1>(")
     entry = {
         "kernel": "hybrid_pass_kernel (mean of pass A and pass B)",
         "n": n,

@@ -1080,7 +1080,7 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     a.status = plan->status;
     a.tile_counter = plan->control->tile_counter[kMaxPasses - 2];
     a.index_payload = indexed;
-    if (int rc = hybrid_launch_pass(&a, nullptr, loop ? &ordinary[0] : nullptr, loop, split.windowed, plan->threads, plan->kpt, hdr,
+    if (int rc = hybrid_launch_pass(0, &a, nullptr, loop ? &ordinary[0] : nullptr, loop, split.windowed, plan->threads, plan->kpt, hdr,
                                     loop ? persistent_grid : num_tiles, s))
         return rc;
     if (int rc = mark(plan, "msd_pass_a", s)) return rc;
@@ -1099,13 +1099,13 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     a.xcd_block = xcd_block * 2;  // chains end with their bucket: larger blocks cost less here (0.834 -> 0.822 ms at 2^28)
     const SegmentTable buckets{plan->hyb_tables->first_tile, plan->hyb_tables->bucket_start, plan->hyb_tables->bucket_start + 1,
                                plan->hyb_tables->sub_start, a.mask + 1u, &hc->hdr.num_tiles_b};
-    if (int rc = hybrid_launch_pass(&a, &buckets, loop ? &ordinary[1] : nullptr, loop, split.windowed, plan->threads, plan->kpt, hdr,
+    if (int rc = hybrid_launch_pass(1, &a, &buckets, loop ? &ordinary[1] : nullptr, loop, split.windowed, plan->threads, plan->kpt, hdr,
                                     loop ? persistent_grid : static_cast<uint32_t>(hybrid_tiles_b(num_tiles)), s))
         return rc;
     if (int rc = mark(plan, "msd_pass_b", s)) return rc;
     if (!loop) {
         for (uint32_t pass = 0; pass < 2; ++pass) {
-            if (int rc = hybrid_launch_pass(nullptr, nullptr, &ordinary[pass], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
+            if (int rc = hybrid_launch_pass(3, nullptr, nullptr, &ordinary[pass], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
                 return rc;
             if (int rc = mark(plan, "fallback_pass", s)) return rc;
         }
@@ -1144,7 +1144,7 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
         a.xcd_block = xcd_block;
         const SegmentTable oversized{plan->hyb_tables->big_first_tile, plan->hyb_tables->big_start, plan->hyb_tables->big_end,
                                      &hc->big_hist[0][hh][0], 512u, &hc->hdr.num_tiles_big};
-        if (int rc = hybrid_launch_pass(&a, &oversized, &ordinary[2 + hh], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
+        if (int rc = hybrid_launch_pass(2, &a, &oversized, &ordinary[2 + hh], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
             return rc;
         if (int rc = mark(plan, "msd_oversized_pass", s)) return rc;
     }
@@ -1420,6 +1420,20 @@ extern "C" int mrs_morton_encode30_for_sort(mrs_plan* plan, const float* xyz_dev
         return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_morton_encode30_for_sort: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     plan->primed_keys = nullptr;
+    if (plan->hybrid) {
+        // A sort of this size on this plan takes the three-move schedule, whose one read of the keys
+        // counts what BOTH of its pass sequences need (the exact table does not fit beside the
+        // encoder's tiles in LDS, so the encoder cannot leave it): digit histograms counted here
+        // would be thrown away, four LDS atomics per key for nothing.  The plain encoder runs, and
+        // mrs_sort_pairs_primed is then mrs_sort_pairs.
+        HybridSplit split{};
+        if (hybrid_choose_split(plan->desc.begin_bit, plan->desc.end_bit, n, nullptr, plan->aids, &split)) {
+            if (int rc = mrs_morton_encode30(plan->ctx, xyz_dev, n, mn, mx, keys_dev, idx_dev, stream)) return rc;
+            plan->primed_keys = keys_dev;
+            plan->primed_n = n;
+            return MRS_OK;
+        }
+    }
     if (int rc = clear_async(plan->control->ghist, sizeof(plan->control->ghist), s)) return rc;
     {
         const ProfilerRange range("Morton Coding");  // src/main.rs:583

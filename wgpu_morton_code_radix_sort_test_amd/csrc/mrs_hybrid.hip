@@ -22,7 +22,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
 
 // ---- exact 16-bit histogram -----------------------------------------------------------------
 // One LDS atomic per key into 65536 counters of 16 bits, two to a word (128 KiB: one workgroup
-// of 1024 threads per compute unit), 16-byte nontemporal loads, four in flight per thread.  A
+// of 1024 threads per compute unit), 16-byte nontemporal loads, eight in flight per thread (four: 6 % slower).  A
 // workgroup writes its table to `packed`; hybrid_reduce_kernel adds the tables up.
 //
 // The counts are exact whatever the keys are.  A field never wraps: the one add that takes a
@@ -49,7 +49,10 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
                                                                  uint32_t window_base, uint32_t windowed, uint32_t end_bit,
                                                                  uint32_t begin_bit, uint32_t* __restrict__ low_hist)
 {
-    constexpr int THREADS = 1024, UNROLL = 4;
+#ifndef MRS_HYB_HIST_UNROLL
+#define MRS_HYB_HIST_UNROLL 8
+#endif
+    constexpr int THREADS = 1024, UNROLL = MRS_HYB_HIST_UNROLL;
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kHybPackedWords];
     __shared__ uint32_t s_low[2][256 * kLowCopies];
     __shared__ int s_diff;
@@ -68,6 +71,9 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
     const uint32_t low_copy = tid & (kLowCopies - 1);
     // the two lowest digits of the ordinary passes; no result is needed, so no returning atomic
     auto count_low = [&](uint32_t k, uint32_t amount) __attribute__((always_inline)) {
+#ifdef MRS_HYB_NO_LOW  // timing builds only: the ordinary passes of a refused call get no histograms
+        return;
+#endif
         atomicAdd(&s_low[0][__builtin_amdgcn_ubfe(k, begin_bit, 8) * kLowCopies + low_copy], amount);
         atomicAdd(&s_low[1][__builtin_amdgcn_ubfe(k, begin_bit + 8u, 8) * kLowCopies + low_copy], amount);
     };
@@ -662,7 +668,11 @@ __device__ __forceinline__ void gated_pass(const PassArgs& a, const SegmentTable
 }
 
 // SEG: `run` is a pass over the segments of `seg`.  DUAL: `other` exists (persistent launches only).
-template <bool SEG, bool DUAL, bool PERSISTENT, int MAP, int THREADS, int KPT>
+// ROLE names the launch for profilers and changes nothing else (kPassA, kPassB, kPassOversized,
+// kPassOrdinary): without it pass B and the usually idle passes over oversized sub-buckets would be
+// one kernel name, and a profiler's average duration of it would describe neither.
+enum PassRole { kPassA = 0, kPassB = 1, kPassOversized = 2, kPassOrdinary = 3 };
+template <bool SEG, bool DUAL, bool PERSISTENT, int MAP, int THREADS, int KPT, int ROLE>
 __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs run, const SegmentTable seg,
                                                                   const PassArgs other, const HybridHeader* __restrict__ hdr)
 {
@@ -936,21 +946,21 @@ int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, H
     return MRS_OK;
 }
 
-template <bool SEG, bool DUAL, bool PERSISTENT, int MAP>
+template <bool SEG, bool DUAL, bool PERSISTENT, int MAP, int ROLE>
 static int launch_pass_shape(int threads, int kpt, const PassArgs& run, const SegmentTable& seg, const PassArgs& other,
                              const HybridHeader* hdr, uint32_t grid, hipStream_t s)
 {
     if (threads == 1024 && kpt == 32)
-        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 1024, 32>), dim3(grid), dim3(1024), 0, s, run, seg, other, hdr);
+        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 1024, 32, ROLE>), dim3(grid), dim3(1024), 0, s, run, seg, other, hdr);
     else if (threads == 512 && kpt == 8)
-        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 512, 8>), dim3(grid), dim3(512), 0, s, run, seg, other, hdr);
+        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 512, 8, ROLE>), dim3(grid), dim3(512), 0, s, run, seg, other, hdr);
     else
         return fail(MRS_ERR_UNSUPPORTED, "no gated pass kernel for %d threads x %d keys per thread", threads, kpt);
     MRS_CHECK_LAUNCH("hybrid_pass_kernel");
     return MRS_OK;
 }
 
-int hybrid_launch_pass(const PassArgs* run, const SegmentTable* seg, const PassArgs* other, bool persistent, bool windowed,
+int hybrid_launch_pass(int role, const PassArgs* run, const SegmentTable* seg, const PassArgs* other, bool persistent, bool windowed,
                        int threads, int kpt, const HybridHeader* hdr, uint32_t grid, hipStream_t s)
 {
     if (!run && !other) return fail(MRS_ERR_INVALID_ARGUMENT, "a gated pass needs at least one description");
@@ -964,20 +974,34 @@ int hybrid_launch_pass(const PassArgs* run, const SegmentTable* seg, const PassA
     const PassArgs& o = other ? *other : none;
     const bool segmented = run && seg;
     const SegmentTable table = segmented ? *seg : SegmentTable{};
-    if (persistent) {  // passes of a sort that shares the device with nothing: plain bit-field digits
-        if (windowed) return fail(MRS_ERR_UNSUPPORTED, "persistent gated passes take plain bit-field digits");
-        if (other)
-            return segmented ? launch_pass_shape<true, true, true, kMapNone>(threads, kpt, r, table, o, hdr, grid, s)
-                             : launch_pass_shape<false, true, true, kMapNone>(threads, kpt, r, table, o, hdr, grid, s);
-        return segmented ? launch_pass_shape<true, false, true, kMapNone>(threads, kpt, r, table, o, hdr, grid, s)
-                         : launch_pass_shape<false, false, true, kMapNone>(threads, kpt, r, table, o, hdr, grid, s);
+    switch (role) {
+        case kPassA:  // over the whole array
+            if (segmented) break;
+            if (persistent) {
+                if (windowed || !other) break;
+                return launch_pass_shape<false, true, true, kMapNone, kPassA>(threads, kpt, r, table, o, hdr, grid, s);
+            }
+            if (other) break;
+            return windowed ? launch_pass_shape<false, false, false, kMapWindow, kPassA>(threads, kpt, r, table, o, hdr, grid, s)
+                            : launch_pass_shape<false, false, false, kMapNone, kPassA>(threads, kpt, r, table, o, hdr, grid, s);
+        case kPassB:  // bucket by bucket
+            if (!segmented) break;
+            if (persistent) {
+                if (windowed || !other) break;
+                return launch_pass_shape<true, true, true, kMapNone, kPassB>(threads, kpt, r, table, o, hdr, grid, s);
+            }
+            if (other) break;
+            return windowed ? launch_pass_shape<true, false, false, kMapWindow, kPassB>(threads, kpt, r, table, o, hdr, grid, s)
+                            : launch_pass_shape<true, false, false, kMapNone, kPassB>(threads, kpt, r, table, o, hdr, grid, s);
+        case kPassOversized:  // plain digits, persistent, always beside an ordinary pass
+            if (!segmented || !persistent || windowed || !other) break;
+            return launch_pass_shape<true, true, true, kMapNone, kPassOversized>(threads, kpt, r, table, o, hdr, grid, s);
+        case kPassOrdinary:  // an ordinary pass with a launch of its own
+            if (run || !persistent || windowed) break;
+            return launch_pass_shape<false, true, true, kMapNone, kPassOrdinary>(threads, kpt, r, table, o, hdr, grid, s);
+        default: break;
     }
-    if (other) return fail(MRS_ERR_UNSUPPORTED, "a pass with a workgroup per tile serves one schedule");
-    if (windowed)
-        return segmented ? launch_pass_shape<true, false, false, kMapWindow>(threads, kpt, r, table, o, hdr, grid, s)
-                         : launch_pass_shape<false, false, false, kMapWindow>(threads, kpt, r, table, o, hdr, grid, s);
-    return segmented ? launch_pass_shape<true, false, false, kMapNone>(threads, kpt, r, table, o, hdr, grid, s)
-                     : launch_pass_shape<false, false, false, kMapNone>(threads, kpt, r, table, o, hdr, grid, s);
+    return fail(MRS_ERR_UNSUPPORTED, "no gated pass kernel for this combination (role %d)", role);
 }
 
 int hybrid_launch_big_histogram(const uint32_t* keys, const HybridTables* tables, HybridCleared* hc, uint32_t tile_items,

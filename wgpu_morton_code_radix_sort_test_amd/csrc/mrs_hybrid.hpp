@@ -128,7 +128,9 @@ int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, H
 // persistent: `grid` workgroups draw tiles until none is left (a launch with nothing to do then
 // costs `grid` workgroups, not one per tile); a launch with a workgroup per tile serves `run` only.
 // windowed: the digits are fields of (key >> shift) - window_base (PassArgs).
-int hybrid_launch_pass(const PassArgs* run, const SegmentTable* seg, const PassArgs* other, bool persistent, bool windowed,
+// role: which launch of the schedule this is (0 pass A, 1 pass B, 2 a pass over the oversized
+// sub-buckets, 3 an ordinary pass on its own); it selects the kernel's name, nothing else.
+int hybrid_launch_pass(int role, const PassArgs* run, const SegmentTable* seg, const PassArgs* other, bool persistent, bool windowed,
                        int threads, int kpt, const HybridHeader* hdr, uint32_t grid, hipStream_t s);
 // Digit counts of the oversized sub-buckets on bits [shift, shift + bits1) and the bits2 above
 // them, and their scan into run positions (two launches).
