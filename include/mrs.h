@@ -148,6 +148,13 @@ int mrs_context_destroy(mrs_context* ctx);
 #define MRS_ATTR_TEST_NO_PASS_SKIP 9          /* 1: 64-bit keys run every pass (src/main.rs:594-665)     */
 #define MRS_ATTR_TEST_WIDE_STATUS 10          /* 1: chained-scan plans use the 64-bit tile status words
                                                  of inputs above 2^30 elements at any size              */
+#define MRS_ATTR_TEST_HYBRID_FORCE_ADAPTIVE 11 /* 1: the device passes over the fixed sub-buckets and cuts
+                                                 buckets and groups to the keys (MRS_SCHEDULE_MSD_ADAPTIVE)
+                                                 wherever that schedule is offered                       */
+#define MRS_ATTR_TEST_HYBRID_NO_ADAPTIVE 12   /* 1: that schedule is not offered                          */
+#define MRS_ATTR_TEST_HYBRID_CAPACITY 13      /* pairs a workgroup of the local sort is taken to hold
+                                                 (0: what it holds, 7680 or 10240): smaller values make
+                                                 oversized sub-buckets and many groups out of small inputs */
 int mrs_context_get_attribute(const mrs_context* ctx, int attribute, int64_t* value);
 /* MRS_ATTR_DIE_AWARE_TICKETS can be cleared (value 0) and, where the creation-time check passed,
  * set again.  With die-aware tickets a pass makes progress only if it keeps getting workgroup
@@ -183,8 +190,12 @@ int mrs_plan_get_passes_left_out(mrs_plan* plan, void* stream, uint32_t* left_ou
 /* Synchronises `stream` and reports which pass schedule the most recent sort call on `plan`
  * ran: MRS_SCHEDULE_PASSES (every plan but MRS_ALGO_HYBRID ones, and inputs too small for the
  * other schedule), MRS_SCHEDULE_MSD (an MRS_ALGO_HYBRID plan whose keys the device found spread
- * well enough) or MRS_SCHEDULE_MSD_REFUSED (the device found too many or too full oversized
- * sub-buckets and ran the ordinary passes).  *largest_sub_bucket (may be NULL) receives the size of
+ * well enough), MRS_SCHEDULE_MSD_ADAPTIVE (keys that crowd into few of the fixed sub-buckets, e.g.
+ * points on surfaces: the same three moves, with the two scatters following tables the device cut
+ * to the keys' density -- at most 256 buckets of whole 12-bit cells, each cut into at most 256
+ * groups that fit a workgroup; offered for 28 to 32 sorted bits from bit 0) or
+ * MRS_SCHEDULE_MSD_REFUSED (the device found too many or too full oversized sub-buckets, and no such
+ * cut either, and ran the ordinary passes).  *largest_sub_bucket (may be NULL) receives the size of
  * the largest of the sub-buckets the device counted, 0 when it counted none.  For tests and
  * harnesses; the reference always runs its one schedule (src/main.rs:594-665). */
 /* Host only, no GPU needed: how an MRS_ALGO_HYBRID plan for key bits [begin_bit, end_bit) would
@@ -208,6 +219,7 @@ int mrs_hybrid_split_for(uint64_t n, int32_t begin_bit, int32_t end_bit, const u
 #define MRS_SCHEDULE_PASSES 0
 #define MRS_SCHEDULE_MSD 1
 #define MRS_SCHEDULE_MSD_REFUSED 2
+#define MRS_SCHEDULE_MSD_ADAPTIVE 3
 int mrs_plan_get_schedule(mrs_plan* plan, void* stream, int32_t* schedule, uint32_t* largest_sub_bucket);
 /* Synchronises `stream`.  For the most recent sort call on an MRS_ALGO_HYBRID plan that ran
  * MRS_SCHEDULE_MSD: how many sub-buckets did not fit a workgroup of the local sort and were sorted
@@ -217,6 +229,13 @@ int mrs_plan_get_schedule(mrs_plan* plan, void* stream, int32_t* schedule, uint3
  * otherwise.  Any pointer may be NULL.  For tests and harnesses; no counterpart in the reference. */
 int mrs_plan_get_oversized(mrs_plan* plan, void* stream, uint32_t* sub_buckets, uint64_t* pairs,
                            uint32_t* capacity);
+/* Synchronises `stream`.  For the most recent sort call on an MRS_ALGO_HYBRID plan that ran
+ * MRS_SCHEDULE_MSD_ADAPTIVE: into how many buckets the first scatter divided the keys (*buckets, at
+ * most 256) and into how many groups the second one (*groups, at most 65536; each was sorted by one
+ * visit of a workgroup of the local sort, or, if it was a single oversized cell, by the two extra
+ * passes).  Zeros otherwise.  Either pointer may be NULL.  For tests and harnesses; no counterpart
+ * in the reference. */
+int mrs_plan_get_adaptive(mrs_plan* plan, void* stream, uint32_t* buckets, uint32_t* groups);
 
 /* Measurement hook (the reference has no timers; its passes are named for an
  * external profiler, src/main.rs:583-662).  With timing enabled, mrs_sort_pairs

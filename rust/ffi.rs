@@ -121,6 +121,7 @@ extern "C" {
                                  largest_sub_bucket: *mut u32) -> c_int;
     pub fn mrs_plan_get_oversized(plan: *mut mrs_plan, stream: *mut c_void, sub_buckets: *mut u32, pairs: *mut u64,
                                   capacity: *mut u32) -> c_int;
+    pub fn mrs_plan_get_adaptive(plan: *mut mrs_plan, stream: *mut c_void, buckets: *mut u32, groups: *mut u32) -> c_int;
     pub fn mrs_plan_set_timing(plan: *mut mrs_plan, enable: c_int) -> c_int;
     pub fn mrs_plan_get_timings(plan: *mut mrs_plan, cap: c_int, ms_out: *mut f32, labels_out: *mut c_char,
                                 count_out: *mut c_int) -> c_int;

@@ -69,13 +69,14 @@ def test_full_size_sort_properties(ctx, mrs, log2n, algo_name, bits):
     plan.close()
 
 
-@pytest.mark.parametrize("log2n,end_bit,want", [(28, 30, "msd"), (28, 32, "refused"), (27, 30, "msd"), (26, 30, "msd"),
+@pytest.mark.parametrize("log2n,end_bit,want", [(28, 30, "msd"), (28, 32, "adaptive"), (27, 30, "msd"), (26, 30, "msd"),
                                                 (26, 32, "passes"), (29, 30, "msd")])
 def test_full_size_hybrid_plan_equals_four_passes(ctx, mrs, log2n, end_bit, want):
     """MRS_ALGO_HYBRID plans at the sizes they exist for, against the four-pass plan on the same
     input, pair for pair (a stable sort has one answer), plus the size-independent properties.
-    30-bit codes declared as 32-bit keys leave three quarters of the leading buckets empty: the
-    device refuses and the result is still that of the four passes; 2^26 pairs of 32-bit keys are
+    30-bit codes declared as 32-bit keys leave three quarters of the fixed sub-buckets empty and
+    the rest too full: the device cuts buckets and groups to the keys instead, and the result is
+    still that of the four passes; 2^26 pairs of 32-bit keys are
     below the size the three-move schedule pays for: the host does not enqueue it; 2^29 pairs leave
     sub-buckets of 8192 pairs, which fit a workgroup that stages a pair in 6 bytes."""
     n = 1 << log2n
@@ -93,7 +94,8 @@ def test_full_size_hybrid_plan_equals_four_passes(ctx, mrs, log2n, end_bit, want
     assert not plan.sort_pairs(keys, idx, kb, vb)
     plan.check()
     schedule, largest = plan.schedule()
-    assert schedule == {"msd": plan.SCHEDULE_MSD, "refused": plan.SCHEDULE_MSD_REFUSED, "passes": plan.SCHEDULE_PASSES}[want], largest
+    assert schedule == {"msd": plan.SCHEDULE_MSD, "refused": plan.SCHEDULE_MSD_REFUSED, "passes": plan.SCHEDULE_PASSES,
+                        "adaptive": plan.SCHEDULE_MSD_ADAPTIVE}[want], largest
     assert bool((keys == rk).all()) and bool((idx == rv).all())
     check_sorted_pairs(keys, idx, keys_in)
     # the sort that makes the indices up, and a second call on the plan
@@ -116,7 +118,7 @@ def test_full_size_hybrid_plan_equals_four_passes(ctx, mrs, log2n, end_bit, want
 def _shaped_keys(ctx, n, shape, seed):
     """30-bit codes at sizes the CPU checker is too slow for.  "hot20": a fifth of the keys share their
     16 leading bits (one sub-bucket far beyond any 16-bit counter of the histogram); "cluster": 5 % of
-    the points in a small cube; "surface": points on a sphere shell and on three planes."""
+    the points in a small cube; "surface": points on a sphere shell and on three planes; "equal": one point."""
     xyz = ctx.generate_points(seed, n)
     if shape == "cluster":
         m = n // 20
@@ -130,6 +132,8 @@ def _shaped_keys(ctx, n, shape, seed):
         xyz[half:half + third, 0] = 0.3
         xyz[half + third:half + 2 * third, 1] = 0.55
         xyz[half + 2 * third:, 2] = 0.8
+    elif shape == "equal":
+        xyz[:] = 0.3
     keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
     del xyz
     if shape == "hot20":
@@ -140,15 +144,16 @@ def _shaped_keys(ctx, n, shape, seed):
     return keys, idx
 
 
-@pytest.mark.parametrize("log2n,shape,want", [(26, "hot20", "msd"), (28, "cluster", "msd"), (27, "surface", "refused"),
-                                              (29, "cluster", "msd")])
+@pytest.mark.parametrize("log2n,shape,want", [(26, "hot20", "msd"), (28, "cluster", "msd"), (27, "surface", "adaptive"),
+                                              (28, "surface", "adaptive"), (29, "cluster", "msd"), (28, "equal", "refused")])
 def test_full_size_uneven_keys(ctx, mrs, log2n, shape, want):
     """Inputs whose sub-buckets are far from even, at sizes only the GPU can check: the result must be
     the four-pass plan's, pair for pair, whatever the device decides.  A sub-bucket with a fifth of
     2^26 keys overflows the 16-bit counters of every histogram workgroup many times over (the
     counts must still be exact) and is sorted by the two extra passes; clustered points leave a
-    handful of oversized sub-buckets; points on surfaces leave thousands, and the device takes the
-    ordinary passes with the histograms it already has."""
+    handful of oversized sub-buckets; points on surfaces leave thousands, and the device cuts buckets
+    and groups to the keys' density instead; keys that are all equal cannot be cut at all, and the
+    device takes the ordinary passes with the histograms it already has."""
     n = 1 << log2n
     free_b, _ = torch.cuda.mem_get_info()
     if free_b < 60 * n:
@@ -169,7 +174,11 @@ def test_full_size_uneven_keys(ctx, mrs, log2n, shape, want):
         plan.check()
         schedule, largest = plan.schedule()
         subs, pairs, cap = plan.oversized()
-        assert schedule == (plan.SCHEDULE_MSD if want == "msd" else plan.SCHEDULE_MSD_REFUSED), (largest, subs, pairs)
+        assert schedule == {"msd": plan.SCHEDULE_MSD, "refused": plan.SCHEDULE_MSD_REFUSED,
+                            "adaptive": plan.SCHEDULE_MSD_ADAPTIVE}[want], (largest, subs, pairs)
+        if want == "adaptive":
+            buckets, groups = plan.adaptive()
+            assert 128 <= buckets <= 256 and n // cap <= groups <= 65536, (buckets, groups)
         if want == "msd":
             assert 1 <= subs <= 256 and cap < pairs <= n // 4 and largest > cap, (largest, subs, pairs, cap)
             if shape == "hot20":

@@ -25,6 +25,9 @@ def small_inputs_take_the_schedule(ctx, aids):
     """The library keeps inputs below 2^26 pairs on the ordinary passes; the checker is too slow
     for more, so the tests lower the threshold (a plan reads it from its context at creation)."""
     aids(ctx.ATTR_TEST_HYBRID_MIN_N, 1)
+    # this file is about the fixed sub-buckets and their refusal (tests/test_gpu_hybrid_adaptive.py:
+    # the cut that follows the keys)
+    aids(ctx.ATTR_TEST_HYBRID_NO_ADAPTIVE, 1)
 
 
 def _sort_with_plan(ctx, mrs, keys, vals, n, begin, end, capacity=None, tile_items=0, indexed=False, oversized=None, twice=False):

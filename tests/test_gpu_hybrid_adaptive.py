@@ -1,0 +1,172 @@
+"""GPU parity tests of the adaptive form of the most-significant-digit-first schedule
+(MRS_SCHEDULE_MSD_ADAPTIVE): keys that crowd into few of the fixed sub-buckets are scattered by
+tables the device cuts to their density.  Through the C ABI, bit for bit against the CPU checker's
+stable sort.  The reference sorts codes of triangle centroids (src/main.rs:114-173), which lie on
+surfaces: the inputs here are made like those."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import to_dev, to_u32
+from inputs import make_keys, make_vals
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mrs():
+    import wgpu_morton_code_radix_sort_test_amd as m
+
+    return m
+
+
+@pytest.fixture()
+def small(ctx, aids):
+    aids(ctx.ATTR_TEST_HYBRID_MIN_N, 1)
+
+
+def _sort(ctx, mrs, keys, vals, n, end, twice=False):
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, begin_bit=0, end_bit=end, algo=mrs.ALGO_HYBRID)
+    ka, va = to_dev(keys, ctx.device), to_dev(vals, ctx.device)
+    kb, vb = torch.full_like(ka, -1), torch.full_like(va, -1)
+    in_b = plan.sort_pairs(ka, va, kb, vb, n=n)
+    plan.check()
+    if twice:
+        ka.copy_(to_dev(keys, ctx.device))
+        va.copy_(to_dev(vals, ctx.device))
+        in_b = plan.sort_pairs(ka, va, kb, vb, n=n)
+        plan.check()
+    schedule, largest = plan.schedule()
+    over = plan.oversized()
+    ko, vo = to_u32(kb if in_b else ka)[:n], to_u32(vb if in_b else va)[:n]
+    plan.close()
+    return ko, vo, in_b, schedule, largest, over
+
+
+def _part1by2(v):
+    v = v.astype(np.uint32) & np.uint32(0x3FF)
+    v = (v | (v << np.uint32(16))) & np.uint32(0x030000FF)
+    v = (v | (v << np.uint32(8))) & np.uint32(0x0300F00F)
+    v = (v | (v << np.uint32(4))) & np.uint32(0x030C30C3)
+    v = (v | (v << np.uint32(2))) & np.uint32(0x09249249)
+    return v
+
+
+def _surface_codes(n, seed, shell=0.5, thickness=0.0):
+    """30-bit Morton codes of points on a sphere shell (`shell` of them) and on three axis-aligned planes."""
+    rng = np.random.default_rng(seed)
+    xyz = rng.random((n, 3), dtype=np.float32)
+    half = int(n * shell)
+    d = xyz[:half] - 0.5
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-6)
+    xyz[:half] = 0.5 + (0.45 + thickness * rng.standard_normal((half, 1)).astype(np.float32)) * d
+    third = (n - half) // 3
+    xyz[half:half + third, 0] = 0.3
+    xyz[half + third:half + 2 * third, 1] = 0.55
+    xyz[half + 2 * third:, 2] = 0.8
+    q = np.clip((xyz * 1024).astype(np.int64), 0, 1023)
+    return np.ascontiguousarray((_part1by2(q[:, 0]) << np.uint32(2)) | (_part1by2(q[:, 1]) << np.uint32(1)) | _part1by2(q[:, 2]))
+
+
+@pytest.mark.parametrize("n", [5000, 70001, 300007, (1 << 20) + 77, 3000003])
+@pytest.mark.parametrize("end,dist", [(30, "morton30"), (28, "morton30"), (32, "one_hot_digit")])
+def test_forced_on_spread_keys(ctx, oracle, mrs, small, aids, n, end, dist):
+    """The device passes over the fixed sub-buckets; buckets and groups are cut to the keys."""
+    aids(ctx.ATTR_TEST_HYBRID_FORCE_ADAPTIVE, 1)
+    keys = make_keys(oracle, n, 1, dist, seed=n)
+    if end == 28:
+        keys = keys >> np.uint32(2)
+    vals = make_vals(oracle, n, 1)
+    ko, vo, in_b, schedule, largest, over = _sort(ctx, mrs, keys, vals, n, end)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, end)
+    assert not in_b
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv), (n, end, dist, schedule)
+    if dist == "morton30":
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD_ADAPTIVE, (n, end, largest, over)
+
+
+@pytest.mark.parametrize("n,capacity", [(400003, 0), (400003, 2048), (400003, 24), (2500000, 0), (2500000, 300), (2500000, 150)])
+def test_points_on_surfaces(ctx, oracle, mrs, small, aids, n, capacity):
+    """Codes of points on a sphere shell and three planes: with a workgroup taken to hold few pairs
+    the fixed sub-buckets are refused at these sizes as they are at 2^28 pairs with the real
+    capacity, and the adaptive cut takes over by the device's own decision."""
+    aids(ctx.ATTR_TEST_HYBRID_CAPACITY, capacity)
+    keys = _surface_codes(n, seed=n + capacity)
+    vals = make_vals(oracle, n, 1)
+    ko, vo, in_b, schedule, largest, over = _sort(ctx, mrs, keys, vals, n, 30, twice=True)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 30)
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv), (n, capacity, schedule)
+    if 0 < capacity <= 300:
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD_ADAPTIVE, (n, capacity, largest, over)
+        assert over[2] == capacity
+
+
+def test_heavy_duplicates_become_oversized_fine_cells(ctx, oracle, mrs, small, aids):
+    """A few key values with more copies than a workgroup holds: fine cells that cannot be cut are
+    sorted where they lie by the two extra passes, inside the adaptive schedule."""
+    aids(ctx.ATTR_TEST_HYBRID_CAPACITY, 500)
+    aids(ctx.ATTR_TEST_HYBRID_FORCE_ADAPTIVE, 1)
+    n = 600011
+    keys = _surface_codes(n, seed=11)
+    rng = np.random.default_rng(3)
+    for j, copies in enumerate([501, 900, 5000, 20000]):
+        at = rng.integers(0, n - copies)
+        keys[at:at + copies] = keys[at]
+    keys = np.ascontiguousarray(keys[rng.permutation(n)])
+    vals = make_vals(oracle, n, 1)
+    ko, vo, in_b, schedule, largest, over = _sort(ctx, mrs, keys, vals, n, 30)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 30)
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv), schedule
+    assert schedule == mrs.SortPlan.SCHEDULE_MSD_ADAPTIVE, (largest, over)
+    assert over[0] >= 4 and over[1] >= 501 + 900 + 5000 + 20000
+
+
+def test_a_bucket_that_cannot_be_cut_hands_over_to_the_ordinary_passes(ctx, oracle, mrs, small, aids):
+    """32 sorted bits, keys in every one of the 65536 cells of the leading 16: a bucket of 1/224 of
+    the keys spans about 290 of them and a group never spans two, so the bucket needs more than 256
+    groups.  The device finds out after pass A and the ordinary passes sort the input."""
+    aids(ctx.ATTR_TEST_HYBRID_FORCE_ADAPTIVE, 1)
+    n = 1 << 20
+    keys = make_keys(oracle, n, 1, "random", seed=5)
+    vals = make_vals(oracle, n, 1)
+    ko, vo, in_b, schedule, largest, over = _sort(ctx, mrs, keys, vals, n, 32)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 32)
+    assert schedule == mrs.SortPlan.SCHEDULE_MSD_REFUSED
+    assert not in_b
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+def test_all_equal_and_few_values(ctx, oracle, mrs, small, aids):
+    aids(ctx.ATTR_TEST_HYBRID_FORCE_ADAPTIVE, 1)
+    n = 200003
+    for dist in ("all_equal", "few_distinct", "sorted", "reversed", "one_hot_digit"):
+        keys = make_keys(oracle, n, 1, dist) & np.uint32(0x3FFFFFFF)
+        vals = make_vals(oracle, n, 1)
+        ko, vo, in_b, schedule, largest, over = _sort(ctx, mrs, keys, vals, n, 30)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 30)
+        assert np.array_equal(ko, rk) and np.array_equal(vo, rv), (dist, schedule)
+
+
+def test_constant_bits_above_the_sorted_range(ctx, oracle, mrs, small, aids):
+    """Bits above end_bit that are the same in every key are carried along (cells are numbered by
+    the sorted bits only)."""
+    aids(ctx.ATTR_TEST_HYBRID_FORCE_ADAPTIVE, 1)
+    n = 150001
+    keys = _surface_codes(n, seed=9) | np.uint32(0x80000000)
+    vals = make_vals(oracle, n, 1)
+    ko, vo, in_b, schedule, largest, over = _sort(ctx, mrs, keys, vals, n, 30)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 30)
+    assert schedule == mrs.SortPlan.SCHEDULE_MSD_ADAPTIVE
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+def test_not_offered_when_switched_off(ctx, oracle, mrs, small, aids):
+    aids(ctx.ATTR_TEST_HYBRID_CAPACITY, 150)
+    aids(ctx.ATTR_TEST_HYBRID_NO_ADAPTIVE, 1)
+    n = 2500000
+    keys = _surface_codes(n, seed=1)
+    vals = make_vals(oracle, n, 1)
+    ko, vo, in_b, schedule, largest, over = _sort(ctx, mrs, keys, vals, n, 30)
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 30)
+    assert schedule == mrs.SortPlan.SCHEDULE_MSD_REFUSED
+    assert np.array_equal(ko, rk) and np.array_equal(vo, rv)

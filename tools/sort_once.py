@@ -30,6 +30,15 @@ def surface_points(xyz, dist):
         xyz[:third, 0] = 0.3
         xyz[third:2 * third, 1] = 0.55
         xyz[2 * third:, 2] = 0.8
+    elif dist == "surface":  # bench.py's "surface" input: half shell, half planes
+        half = n // 2
+        d = xyz[:half] - 0.5
+        d /= d.norm(dim=1, keepdim=True).clamp_min(1e-6)
+        xyz[:half] = 0.5 + 0.45 * d
+        third = (n - half) // 3
+        xyz[half:half + third, 0] = 0.3
+        xyz[half + third:half + 2 * third, 1] = 0.55
+        xyz[half + 2 * third:, 2] = 0.8
 
 
 def main():
@@ -43,10 +52,12 @@ def main():
     ap.add_argument("--key-words", type=int, default=1)
     ap.add_argument("--end-bit", type=int, default=0, help="one past the last key bit sorted on (0: the whole key)")
     ap.add_argument("--payload-bytes", type=int, default=4)
-    ap.add_argument("--dist", default="morton30", choices=["morton30", "random", "sorted", "equal", "cluster5", "shell", "planes"],
+    ap.add_argument("--dist", default="morton30", choices=["morton30", "random", "sorted", "equal", "cluster5", "shell", "planes", "dup64", "surface"],
                     help="morton30: codes of uniform points; cluster5: the same with 5 %% of the points in a small cube; "
                          "shell / planes: codes of points on a sphere shell / on three axis-aligned planes")
     ap.add_argument("--leading-bits", type=int, default=0, help="MRS_ATTR_TEST_HYBRID_LEADING_BITS (14..16; 0 = the library's choice)")
+    ap.add_argument("--adaptive", default="auto", choices=["auto", "force", "off"],
+                    help="hybrid plans: the cut that follows the keys' density is the device's choice, forced, or not offered")
     ap.add_argument("--hi-mask", type=lambda v: int(v, 0), default=0xFFFFFFFF,
                     help="64-bit keys: mask applied to the high word (short codes have constant high bytes)")
     ap.add_argument("--gather", action="store_true",
@@ -55,6 +66,10 @@ def main():
     ctx = mrs.Context(0)
     if args.leading_bits:
         ctx.set_attribute(ctx.ATTR_TEST_HYBRID_LEADING_BITS, args.leading_bits)
+    if args.adaptive == "force":
+        ctx.set_attribute(ctx.ATTR_TEST_HYBRID_FORCE_ADAPTIVE, 1)
+    elif args.adaptive == "off":
+        ctx.set_attribute(ctx.ATTR_TEST_HYBRID_NO_ADAPTIVE, 1)
     n = args.n or (1 << args.log2n)
     algo = {"onesweep": mrs.ALGO_ONESWEEP, "hybrid": mrs.ALGO_HYBRID}.get(args.algo, mrs.ALGO_THREE_KERNEL)
     plan = mrs.SortPlan(ctx, n, key_words=args.key_words, payload_bytes=4 if args.gather else args.payload_bytes,
@@ -66,12 +81,14 @@ def main():
     vb = torch.empty(max(1, n * pw), dtype=torch.int32, device=ctx.device)
     rows = []
     for it in range(args.iters):
-        if args.dist in ("morton30", "cluster5", "shell", "planes"):
+        if args.dist in ("morton30", "cluster5", "shell", "planes", "dup64", "surface"):
             xyz = ctx.generate_points(7 + it, n)
             mn, mx = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
             surface_points(xyz, args.dist)
             keys, idx = ctx.morton_encode30(xyz, mn, mx)
             del xyz
+            if args.dist == "dup64":  # evenly spread codes, 64 copies of each on average
+                keys &= ~0x3F
             if kw == 2:
                 hi = ctx.generate_u32(3, it, n)
                 if args.hi_mask != 0xFFFFFFFF:
@@ -103,8 +120,10 @@ def main():
     if algo == mrs.ALGO_HYBRID:
         schedule, largest = plan.schedule()
         subs, pairs, cap = plan.oversized()
-        extra = {"schedule": {0: "passes", 1: "msd", 2: "msd refused by the device"}[schedule], "largest_sub_bucket": largest,
+        extra = {"schedule": {0: "passes", 1: "msd", 2: "msd refused by the device", 3: "msd adaptive"}[schedule], "largest_sub_bucket": largest,
                  "oversized_sub_buckets": subs, "oversized_pairs": pairs, "workgroup_capacity": cap}
+        if schedule == 3:
+            extra["adaptive_buckets"], extra["adaptive_groups"] = plan.adaptive()
     print(json.dumps({"n": n, "dist": args.dist, "tile_items": plan.info.tile_items, "threads": plan.info.threads,
                       "launches": [(lab, round(ms, 4)) for lab, ms in last], "total_ms": round(total, 4),
                       "gkeys_per_s": round(n / total / 1e6, 3), **extra}))

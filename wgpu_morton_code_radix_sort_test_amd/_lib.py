@@ -113,6 +113,7 @@ SIGNATURES = {
     "mrs_plan_get_schedule": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint32)]),
     "mrs_plan_get_oversized": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64),
                                               ctypes.POINTER(ctypes.c_uint32)]),
+    "mrs_plan_get_adaptive": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     "mrs_plan_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mrs_plan_get_timings": (ctypes.c_int, [_vp, ctypes.c_int, _fp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
     "mrs_morton_encode_lut": (ctypes.c_int, [_vp, _vp, _vp, _u64, _vp, _u64, _vp, _vp]),

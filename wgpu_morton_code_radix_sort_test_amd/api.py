@@ -75,6 +75,9 @@ class Context:
     ATTR_TEST_NO_SMALL_SORT = 8
     ATTR_TEST_NO_PASS_SKIP = 9
     ATTR_TEST_WIDE_STATUS = 10
+    ATTR_TEST_HYBRID_FORCE_ADAPTIVE = 11
+    ATTR_TEST_HYBRID_NO_ADAPTIVE = 12
+    ATTR_TEST_HYBRID_CAPACITY = 13
     NOALLOC_MAX_N = 1 << 26
 
     def attribute(self, which):
@@ -372,6 +375,7 @@ class SortPlan:
     SCHEDULE_PASSES = 0
     SCHEDULE_MSD = 1
     SCHEDULE_MSD_REFUSED = 2
+    SCHEDULE_MSD_ADAPTIVE = 3
 
     def schedule(self, stream=None):
         """`mrs_plan_get_schedule`: synchronises; (schedule the last sort ran, largest sub-bucket the
@@ -387,3 +391,10 @@ class SortPlan:
         _lib.check(self.lib.mrs_plan_get_oversized(self._h, _stream(stream), ctypes.byref(subs), ctypes.byref(pairs),
                                                    ctypes.byref(cap)))
         return subs.value, pairs.value, cap.value
+
+    def adaptive(self, stream=None):
+        """`mrs_plan_get_adaptive`: synchronises; (buckets, groups) the last sort was cut into if it
+        ran SCHEDULE_MSD_ADAPTIVE, else zeros."""
+        buckets, groups = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        _lib.check(self.lib.mrs_plan_get_adaptive(self._h, _stream(stream), ctypes.byref(buckets), ctypes.byref(groups)))
+        return buckets.value, groups.value

@@ -254,10 +254,10 @@ static uint32_t pass_mask(const mrs_plan* p, uint32_t pass)
 // Consecutive tiles are handed to workgroups of the same die in blocks of this many, so that the
 // output lines two neighbouring tiles share meet in one L2 (8 % of the pass time at 2^28 pairs).
 // Blocks must stay well below the tiles a die has in flight (32 with one workgroup per compute
-// unit), or the dies wait for each other.  0 = a single ticket list; MRS_XCD_BLOCK: tuning aid.
+// unit), or the dies wait for each other.  0 = a single ticket list.
 static uint32_t xcd_block_tiles(const mrs_context* ctx)
 {
-    static const int env = std::getenv("MRS_XCD_BLOCK") ? std::atoi(std::getenv("MRS_XCD_BLOCK")) : -1;
+    const int env = ctx->tuning.xcd_block;
     if (!ctx->die_aware_tickets) return 0;
     return env >= 0 ? static_cast<uint32_t>(env > 64 ? 64 : env) : 8u;  // larger blocks only make the dies wait
 }
@@ -369,18 +369,17 @@ static int launch_global_hist(const mrs_plan* p, const GlobalHistArgs& a, hipStr
     const ProfilerRange range("Histogram calculation");  // src/main.rs:597
     const uint64_t vec = p->desc.key_words == 1 ? 4 : 2;
     // Every workgroup ends with up to passes x radix atomic adds on the same global words, so
-    // each gets at least 8 vectors per thread to amortise them (MRS_HIST_BLOCKS_PER_CU: tuning aid).
-    static const uint64_t per_cu = std::getenv("MRS_HIST_BLOCKS_PER_CU") ? std::atoi(std::getenv("MRS_HIST_BLOCKS_PER_CU")) : 16;
+    // each gets at least 8 vectors per thread to amortise them.
+    const uint64_t per_cu = p->ctx->tuning.hist_blocks_per_cu;
     uint64_t blocks = (a.n / vec + 256 * 8 - 1) / (256 * 8);
     const uint64_t cap = static_cast<uint64_t>(p->ctx->num_cus) * per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     // The sorts use the kernel with bank-spread counters: 1024 threads and 64 KiB of LDS per
     // workgroup, one per compute unit (two measured 2-3 % slower), at least 4 vectors per thread
-    // (MRS_HIST_PLAIN=1: A/B aid; MRS_HIST_BANKED_PER_CU: tuning aid).
-    static const bool plain = std::getenv("MRS_HIST_PLAIN") != nullptr;
-    static const uint64_t banked_per_cu =
-        std::getenv("MRS_HIST_BANKED_PER_CU") ? std::atoi(std::getenv("MRS_HIST_BANKED_PER_CU")) : 1;
+    // (mrs::Tuning: the plain kernel instead, more workgroups).
+    const bool plain = p->ctx->tuning.hist_plain;
+    const uint64_t banked_per_cu = p->ctx->tuning.hist_banked_per_cu;
     uint64_t banked = 0;
     if (!plain) {
         banked = (a.n / vec + 1024 * 4 - 1) / (1024 * 4);
@@ -505,7 +504,6 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(MRS_ERR_UNSUPPORTED, "mrs_context_create: device %d is %s; this library is built for gfx950 only",
                     device_id, prop.gcnArchName);
-    // Which ranking the digit passes use on this device (MRS_RANK=match skips the faster one).
     if (device_id >= kMaxDevices)
         return fail(MRS_ERR_UNSUPPORTED, "mrs_context_create: at most %d devices are supported", kMaxDevices);
     bool in_order = false, all_dies = false;
@@ -547,6 +545,12 @@ extern "C" int mrs_context_create(int device_id, mrs_context** out)
     c->lds_atomic_probe_passed = in_order;
     c->workgroups_on_all_dies = all_dies;
     c->die_aware_tickets = all_dies;
+    // tuning aids of profiling scripts: read here, never inside a sort call (MRS_TILE_SHAPE: at the
+    // first plan creation)
+    if (const char* e = std::getenv("MRS_XCD_BLOCK")) c->tuning.xcd_block = std::atoi(e);
+    if (const char* e = std::getenv("MRS_HIST_BLOCKS_PER_CU")) c->tuning.hist_blocks_per_cu = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("MRS_HIST_BANKED_PER_CU")) c->tuning.hist_banked_per_cu = std::max(1, std::atoi(e));
+    c->tuning.hist_plain = std::getenv("MRS_HIST_PLAIN") != nullptr;
     c->live_plans = 0;
     c->static_scratch = scratch_ptr;
     *out = c;
@@ -578,6 +582,9 @@ extern "C" int mrs_context_get_attribute(const mrs_context* ctx, int attribute, 
         case MRS_ATTR_TEST_NO_SMALL_SORT: *value = ctx->aids.no_small_sort ? 1 : 0; return MRS_OK;
         case MRS_ATTR_TEST_NO_PASS_SKIP: *value = ctx->aids.no_pass_skip ? 1 : 0; return MRS_OK;
         case MRS_ATTR_TEST_WIDE_STATUS: *value = ctx->aids.wide_status ? 1 : 0; return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_FORCE_ADAPTIVE: *value = ctx->aids.hybrid_force_adaptive ? 1 : 0; return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_NO_ADAPTIVE: *value = ctx->aids.hybrid_no_adaptive ? 1 : 0; return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_CAPACITY: *value = ctx->aids.hybrid_capacity; return MRS_OK;
         default: return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_get_attribute: unknown attribute %d", attribute);
     }
 }
@@ -615,6 +622,13 @@ extern "C" int mrs_context_set_attribute(mrs_context* ctx, int attribute, int64_
         case MRS_ATTR_TEST_NO_SMALL_SORT: ctx->aids.no_small_sort = value != 0; return MRS_OK;
         case MRS_ATTR_TEST_NO_PASS_SKIP: ctx->aids.no_pass_skip = value != 0; return MRS_OK;
         case MRS_ATTR_TEST_WIDE_STATUS: ctx->aids.wide_status = value != 0; return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_FORCE_ADAPTIVE: ctx->aids.hybrid_force_adaptive = value != 0; return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_NO_ADAPTIVE: ctx->aids.hybrid_no_adaptive = value != 0; return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_CAPACITY:
+            if (value < 0 || value > kHybLocalCapCompact)
+                return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_set_attribute: capacity must be 0 (default) or 1..%u", kHybLocalCapCompact);
+            ctx->aids.hybrid_capacity = static_cast<uint32_t>(value);
+            return MRS_OK;
         default: return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_set_attribute: attribute %d cannot be set", attribute);
     }
 }
@@ -701,15 +715,21 @@ static uint64_t hybrid_tiles_big(uint64_t num_tiles) { return num_tiles / 4 + kH
 
 // Status-word bytes one call on `num_tiles` tiles uses (and clears).  The two schedules of a
 // hybrid plan never run in the same call, so they share the space: pass A takes the first pass
-// region, pass B what follows it, the passes over oversized sub-buckets what follows that.
+// region, pass B what follows it, the passes over oversized sub-buckets what follows that.  Pass A
+// of the adaptive schedule has a region behind all of that: the ordinary passes may still run
+// after it, and they need theirs untouched.
+static size_t hybrid_adaptive_status_offset(const mrs_plan* p, uint64_t num_tiles)
+{
+    const size_t per_tile = static_cast<size_t>(p->radix) * p->status_word_bytes;
+    const size_t passes = num_tiles * per_tile * p->num_passes;
+    const size_t msd = (num_tiles + hybrid_tiles_b(num_tiles) + 2 * hybrid_tiles_big(num_tiles)) * per_tile;
+    return msd > passes ? msd : passes;
+}
 static size_t status_bytes(const mrs_plan* p, uint64_t num_tiles)
 {
     const size_t per_tile = static_cast<size_t>(p->radix) * p->status_word_bytes;
     size_t bytes = num_tiles * per_tile * p->num_passes;
-    if (p->hybrid) {
-        const size_t msd = (num_tiles + hybrid_tiles_b(num_tiles) + 2 * hybrid_tiles_big(num_tiles)) * per_tile;
-        if (msd > bytes) bytes = msd;
-    }
+    if (p->hybrid) bytes = hybrid_adaptive_status_offset(p, num_tiles) + num_tiles * per_tile;
     return align_up(bytes, 256);
 }
 
@@ -866,7 +886,7 @@ extern "C" int mrs_plan_get_schedule(mrs_plan* plan, void* stream, int32_t* sche
     if (!plan->hyb_last) return MRS_OK;
     HybridHeader h;
     MRS_HIP_TRY(hipMemcpy(&h, &plan->hyb_cleared->hdr, sizeof h, hipMemcpyDeviceToHost));
-    *schedule = h.mode == kHybRun ? MRS_SCHEDULE_MSD : MRS_SCHEDULE_MSD_REFUSED;
+    *schedule = h.mode == kHybRun ? MRS_SCHEDULE_MSD : (h.mode == kHybAdapt ? MRS_SCHEDULE_MSD_ADAPTIVE : MRS_SCHEDULE_MSD_REFUSED);
     if (largest_sub_bucket) *largest_sub_bucket = h.max_sub;
     return MRS_OK;
 }
@@ -885,8 +905,25 @@ extern "C" int mrs_plan_get_oversized(mrs_plan* plan, void* stream, uint32_t* su
     HybridHeader h;
     MRS_HIP_TRY(hipMemcpy(&h, &plan->hyb_cleared->hdr, sizeof h, hipMemcpyDeviceToHost));
     if (sub_buckets) *sub_buckets = h.num_big;
-    if (pairs) *pairs = h.mode == kHybRun ? h.big_pairs : 0;
-    if (capacity) *capacity = plan->hyb_compact_ok ? kHybLocalCapCompact : kHybLocalCapFull;
+    if (pairs) *pairs = (h.mode == kHybRun || h.mode == kHybAdapt) ? h.big_pairs : 0;
+    if (capacity) *capacity = plan->hyb_cap;
+    return MRS_OK;
+}
+
+extern "C" int mrs_plan_get_adaptive(mrs_plan* plan, void* stream, uint32_t* buckets, uint32_t* groups)
+{
+    clear_error();
+    if (!plan) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_plan_get_adaptive: null plan");
+    if (int rc = check_device(plan->ctx, "mrs_plan_get_adaptive")) return rc;
+    if (buckets) *buckets = 0;
+    if (groups) *groups = 0;
+    MRS_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (!plan->hyb_last) return MRS_OK;
+    HybridHeader h;
+    MRS_HIP_TRY(hipMemcpy(&h, &plan->hyb_cleared->hdr, sizeof h, hipMemcpyDeviceToHost));
+    if (h.mode != kHybAdapt) return MRS_OK;
+    if (buckets) *buckets = h.adapt_buckets;
+    if (groups) *groups = h.adapt_groups;
     return MRS_OK;
 }
 
@@ -1005,7 +1042,11 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     const uint32_t begin_bit = plan->desc.begin_bit, end_bit = plan->desc.end_bit;
     const int hist_grid = hybrid_histogram_grid(plan->ctx->num_cus, n32);
     const uint32_t msd_bits = split.msd_bits;
+#ifdef MRS_SWAP_AB  // A/B builds: pass A takes the smaller half
+    const uint32_t bits_a = msd_bits / 2, bits_b = msd_bits - bits_a;
+#else
     const uint32_t bits_a = (msd_bits + 1) / 2, bits_b = msd_bits - bits_a;  // 7 or 8 each
+#endif
     // a pair of a sub-bucket can be staged as 16 key bits + payload if nothing below the
     // sub-bucket's own bits is lost that way (the device still has a say: bits above end_bit)
 #ifdef MRS_NO_COMPACT  // A/B builds: 8-byte staging everywhere
@@ -1014,6 +1055,27 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     const bool compact_ok = split.shift <= 16u;
 #endif
     plan->hyb_compact_ok = compact_ok;
+    uint32_t cap = compact_ok ? kHybLocalCapCompact : kHybLocalCapFull;
+    if (plan->aids.hybrid_capacity != 0 && plan->aids.hybrid_capacity < cap) cap = plan->aids.hybrid_capacity;  // test aid
+    plan->hyb_cap = cap;
+    // Passes loop over tiles with one workgroup per compute unit where that costs nothing (same time
+    // per pass within 1 %): a launch with nothing to do is then 256 workgroups instead of 8448 (0.005
+    // against 0.10 ms), and one launch can serve several schedules.  Not inside a sharded sort, whose
+    // exchange kernels on the other stream would wait for the compute units until a pass ends: there
+    // passes A and B get a workgroup per tile and launches of their own.
+    const bool loop = !split.windowed && plan->lineage == nullptr;
+    // The adaptive schedule (buckets and groups cut to the keys' density) is offered where a group,
+    // which lies inside one cell of the 16 bits above begin_bit, can be staged in 6 bytes per pair and
+    // the 4096 cells of the leading 12 bits are made of such cells: 28 to 32 sorted bits from bit 0.
+    AdaptArgs adapt{};
+    adapt.offered = loop && compact_ok && begin_bit == 0 && end_bit >= 28 && !plan->aids.hybrid_no_adaptive;
+    adapt.force = adapt.offered && plan->aids.hybrid_force_adaptive;
+    adapt.cell_shift = end_bit - kAdaptCellBits;
+    adapt.low16_shift = begin_bit + 16u;
+    // a bucket is cut into at most 256 groups of at most `cap` pairs, which greedy cuts fill to three
+    // quarters and more: two thirds of 256 full groups is what a bucket may hold
+    adapt.bucket_max = cap * 170u;
+    adapt.msd_bits = msd_bits;
     HybridCleared* hc = plan->hyb_cleared;
     const HybridHeader* hdr = &hc->hdr;
     // the same read of the keys counts the two lowest digits of the plan's ordinary passes
@@ -1026,17 +1088,11 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     // ... and a decision against the schedule leaves the digit prefix sums of all four ordinary passes
     // behind (the upper two digits are sums over the exact table): no second read of the keys
     if (int rc = hybrid_launch_scan(plan->hyb_packed, hist_grid, plan->hyb_tables, hc, n32, plan->tile_items, force, bits_b,
-                                    compact_ok, plan->control->ghist, begin_bit, end_bit, split.shift, split.windowed ? split.base : 0u,
-                                    s))
+                                    compact_ok, cap, adapt, plan->control->ghist, begin_bit, end_bit, split.shift,
+                                    split.windowed ? split.base : 0u, s))
         return rc;
     if (int rc = mark(plan, "msd_scan", s)) return rc;
 
-    // Passes loop over tiles with one workgroup per compute unit where that costs nothing (same time
-    // per pass within 1 %): a launch with nothing to do is then 256 workgroups instead of 8448 (0.005
-    // against 0.10 ms), and one launch can serve both schedules.  Not inside a sharded sort, whose
-    // exchange kernels on the other stream would wait for the compute units until a pass ends: there
-    // passes A and B get a workgroup per tile and launches of their own.
-    const bool loop = !split.windowed && plan->lineage == nullptr;
     const uint32_t cus = static_cast<uint32_t>(plan->ctx->num_cus);
     const uint32_t persistent_grid = num_tiles < cus ? num_tiles : cus;
     // the plan's ordinary passes, for inputs the device found unfit
@@ -1080,10 +1136,26 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     a.status = plan->status;
     a.tile_counter = plan->control->tile_counter[kMaxPasses - 2];
     a.index_payload = indexed;
-    if (int rc = hybrid_launch_pass(0, &a, nullptr, loop ? &ordinary[0] : nullptr, loop, split.windowed, plan->threads, plan->kpt, hdr,
-                                    loop ? persistent_grid : num_tiles, s))
+    // The same launch holds pass A of the adaptive schedule: by the byte table over the 4096 cells of
+    // the leading 12 bits.  The ordinary passes start one launch later, because that schedule can
+    // still hand over to them when its buckets have been counted.
+    PassArgs aa = a;
+    aa.shift = adapt.cell_shift;
+    aa.mask = kAdaptCells - 1u;
+    aa.digit_map = plan->hyb_tables->map_a;
+    aa.window_base = 0;
+    aa.window_low = 0;
+    aa.status = plan->status + hybrid_adaptive_status_offset(plan, num_tiles);
+    if (int rc = hybrid_launch_pass(0, &a, nullptr, nullptr, loop, split.windowed, plan->threads, plan->kpt, hdr,
+                                    loop ? persistent_grid : num_tiles, s, adapt.offered ? &aa : nullptr, plan->hyb_tables))
         return rc;
     if (int rc = mark(plan, "msd_pass_a", s)) return rc;
+    if (adapt.offered) {
+        if (int rc = hybrid_launch_adapt_count(static_cast<const uint32_t*>(keys_b), plan->hyb_tables, hc, n32, plan->tile_items, cap,
+                                               adapt, s))
+            return rc;
+        if (int rc = mark(plan, "msd_adaptive_count", s)) return rc;
+    }
     // pass B: b -> a by the next digit, bucket by bucket
     a.keys_in = keys_b;
     a.vals_in = vals_b;
@@ -1099,16 +1171,19 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     a.xcd_block = xcd_block * 2;  // chains end with their bucket: larger blocks cost less here (0.834 -> 0.822 ms at 2^28)
     const SegmentTable buckets{plan->hyb_tables->first_tile, plan->hyb_tables->bucket_start, plan->hyb_tables->bucket_start + 1,
                                plan->hyb_tables->sub_start, a.mask + 1u, &hc->hdr.num_tiles_b};
-    if (int rc = hybrid_launch_pass(1, &a, &buckets, loop ? &ordinary[1] : nullptr, loop, split.windowed, plan->threads, plan->kpt, hdr,
-                                    loop ? persistent_grid : static_cast<uint32_t>(hybrid_tiles_b(num_tiles)), s))
+    // ... and pass B of the adaptive schedule: over the same tables, by the groups of each bucket
+    aa = a;
+    aa.shift = adapt.cell_shift;
+    aa.mask = kAdaptCells - 1u;
+    if (int rc = hybrid_launch_pass(1, &a, &buckets, loop ? &ordinary[0] : nullptr, loop, split.windowed, plan->threads, plan->kpt, hdr,
+                                    loop ? persistent_grid : static_cast<uint32_t>(hybrid_tiles_b(num_tiles)), s,
+                                    adapt.offered ? &aa : nullptr, plan->hyb_tables))
         return rc;
     if (int rc = mark(plan, "msd_pass_b", s)) return rc;
     if (!loop) {
-        for (uint32_t pass = 0; pass < 2; ++pass) {
-            if (int rc = hybrid_launch_pass(3, nullptr, nullptr, &ordinary[pass], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
-                return rc;
-            if (int rc = mark(plan, "fallback_pass", s)) return rc;
-        }
+        if (int rc = hybrid_launch_pass(3, nullptr, nullptr, &ordinary[0], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
+            return rc;
+        if (int rc = mark(plan, "fallback_pass", s)) return rc;
     }
     // the remaining bits: two digits, least significant first
     const uint32_t low_bits = split.shift - begin_bit;  // 9..16, or 2..16 under a window
@@ -1116,15 +1191,19 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     // ... of the sub-buckets that fit a workgroup: inside LDS, in place
     if (int rc = hybrid_launch_local_sort(static_cast<uint32_t*>(keys_a), static_cast<uint32_t*>(vals_a), hdr, plan->hyb_tables,
                                           begin_bit, bits1, bits2, 1u << msd_bits, split.shift, compact_ok,
-                                          hybrid_local_sort_grid(plan->ctx->num_cus), s))
+                                          adapt.offered ? adapt.low16_shift : 0u, hybrid_local_sort_grid(plan->ctx->num_cus), s))
         return rc;
     if (int rc = mark(plan, "msd_local_sort", s)) return rc;
     // ... of the oversized ones (the device's list; usually empty, and then these launches are a few
     // hundred workgroups that return at once): their digit counts, then a -> b -> a inside each
     // sub-bucket's own range, one chain per sub-bucket.  Plain bit-field digits also under a window.
     // The same two launches are the last two ordinary passes of the other schedule.
+    // Where the adaptive schedule is offered these passes take the 16 bits above begin_bit in either
+    // schedule (a fixed sub-bucket's own bits end at or below them, and what lies above is constant
+    // inside it).
+    const uint32_t big1 = adapt.offered ? 8u : bits1, big2 = adapt.offered ? 8u : bits2;
     if (int rc = hybrid_launch_big_histogram(static_cast<const uint32_t*>(keys_a), plan->hyb_tables, hc, plan->tile_items,
-                                             begin_bit, bits1, bits2, static_cast<int>(cus), s))
+                                             begin_bit, big1, big2, static_cast<int>(cus), s))
         return rc;
     if (int rc = mark(plan, "msd_oversized_histogram", s)) return rc;
     const size_t big_region = hybrid_tiles_big(num_tiles) * per_tile;
@@ -1133,8 +1212,8 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
         a.vals_in = hh == 0 ? vals_a : vals_b;
         a.keys_out = hh == 0 ? keys_b : keys_a;
         a.vals_out = hh == 0 ? vals_b : vals_a;
-        a.shift = hh == 0 ? begin_bit : begin_bit + bits1;
-        a.mask = (1u << (hh == 0 ? bits1 : bits2)) - 1u;
+        a.shift = hh == 0 ? begin_bit : begin_bit + big1;
+        a.mask = (1u << (hh == 0 ? big1 : big2)) - 1u;
         a.window_base = 0;
         a.window_low = 0;
         a.digit_base = nullptr;
@@ -1144,11 +1223,14 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
         a.xcd_block = xcd_block;
         const SegmentTable oversized{plan->hyb_tables->big_first_tile, plan->hyb_tables->big_start, plan->hyb_tables->big_end,
                                      &hc->big_hist[0][hh][0], 512u, &hc->hdr.num_tiles_big};
-        if (int rc = hybrid_launch_pass(2, &a, &oversized, &ordinary[2 + hh], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
+        if (int rc = hybrid_launch_pass(2, &a, &oversized, &ordinary[1 + hh], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
             return rc;
         if (int rc = mark(plan, "msd_oversized_pass", s)) return rc;
     }
-    return MRS_OK;
+    // the last ordinary pass has a launch of its own
+    if (int rc = hybrid_launch_pass(3, nullptr, nullptr, &ordinary[3], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
+        return rc;
+    return mark(plan, "fallback_pass", s);
 }
 
 // The launch schedule shared by mrs_sort_pairs, mrs_sort_pairs_primed, mrs_sort_pairs_indexed and

@@ -287,8 +287,17 @@ struct OrdinaryDigits {
 
 __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, HybridCleared* hc, uint32_t n,
                                                             uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits,
-                                                            uint32_t compact_ok, const OrdinaryDigits od)
+                                                            uint32_t compact_ok, const uint32_t cap, const AdaptArgs adapt,
+                                                            const OrdinaryDigits od)
 {
+    // the adaptive plan (below): pairs per level-A cell, their running sums, and per candidate bucket
+    // size the cell at which the bucket after the one starting at cell i starts
+    constexpr int kCandidates = 4;
+    __shared__ uint32_t s_cell[kAdaptCells];
+    __shared__ uint32_t s_run[kAdaptCells];
+    __shared__ unsigned short s_nxt[kCandidates][kAdaptCells];
+    __shared__ unsigned short s_bfirst[kCandidates][kHybBuckets + 2];
+    __shared__ uint32_t s_groups[kCandidates], s_maxb[kCandidates];
     __shared__ uint32_t s_wsum[16];
     __shared__ uint32_t s_bigw[16];
     __shared__ uint32_t s_bstart[kHybBuckets + 1];
@@ -300,8 +309,6 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
     __shared__ uint32_t s_max, s_bigpairs, s_mode;
     HybridHeader* hdr = &hc->hdr;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // what a workgroup of the local sort can hold
-    const uint32_t cap = compact_ok != 0u ? kHybLocalCapCompact : kHybLocalCapFull;
     uint32_t c[64];
     {
         const uint4* c4 = reinterpret_cast<const uint4*>(tb->counts) + tid * 16;
@@ -434,8 +441,11 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
             // times and counted twice): the ordinary passes are the better schedule.
             // Nor is a call whose local sort was set up to stage 6 bytes per pair when the keys turn
             // out to differ above the sorted range (the ordinary passes carry any bits along).
-            const bool ok = hdr->overflow == 0 && s_bstart[kHybBuckets] == n && force_mode != kHybFallback &&
-                            total_big <= kHybMaxBig && s_bigpairs <= n / 4u && !(compact_ok != 0u && hdr->high_vary != 0u);
+            const bool sane = hdr->overflow == 0 && s_bstart[kHybBuckets] == n && force_mode != kHybFallback &&
+                              !(compact_ok != 0u && hdr->high_vary != 0u);
+            const bool ok = sane && adapt.force == 0u && total_big <= kHybMaxBig && s_bigpairs <= n / 4u;
+            // refused for the sizes of the sub-buckets only: buckets and groups cut to the keys' density may do
+            const bool try_adapt = sane && !ok && adapt.offered != 0u;
             tb->first_tile[kHybBuckets] = total_tiles;
             tb->big_first_tile[kHybMaxBig] = total_big_tiles;
             hdr->num_tiles_b = ok ? total_tiles : 0u;
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
             hdr->big_pairs = s_bigpairs;
             hdr->max_sub = s_max;
             hdr->mode = ok ? kHybRun : kHybFallback;
-            s_mode = ok ? kHybRun : kHybFallback;
+            s_mode = ok ? kHybRun : (try_adapt ? kHybAdapt : kHybFallback);
         }
     }
     if (tid < 512) (&s_high[0][0])[tid] = 0;
@@ -489,6 +499,491 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
         for (uint32_t w = pass * 4u; w < wave; ++w) off += s_psum[w];
         od.ghist[tid] = off;
     }
+    if (s_mode != kHybAdapt) return;  // uniform
+    // ---- the adaptive plan: at most 256 buckets of whole level-A cells --------------------------
+    // pairs per cell (a cell is 4, 8 or 16 consecutive entries of the exact table)
+    {
+        const uint32_t per_cell = (1u << (adapt.msd_bits - kAdaptCellBits)) - 1u;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            acc += c[q];
+            if ((static_cast<uint32_t>(q + 1) & per_cell) == 0u) {
+                const uint32_t cell = (tid * 64u + static_cast<uint32_t>(q)) >> (adapt.msd_bits - kAdaptCellBits);
+                if (cell < kAdaptCells) s_cell[cell] = acc;
+                acc = 0;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        // s_run[i] = pairs of cells 0 .. i
+        uint32_t v[4], sum4 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] = s_cell[tid * 4u + q];
+            sum4 += v[q];
+        }
+        const uint32_t inc = wave_inclusive_sum(sum4);
+        if (lane == 63) s_psum[wave] = inc;
+        __syncthreads();
+        uint32_t at = inc - sum4;
+        for (uint32_t w = 0; w < wave; ++w) at += s_psum[w];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            at += v[q];
+            s_run[tid * 4u + q] = at;
+            tb->cell_count[tid * 4u + q] = v[q];
+        }
+    }
+    __syncthreads();
+    // first cell whose running sum exceeds x (4096 if none): the first occupied cell behind the cells summed in x
+    auto first_above = [&](uint32_t x) __attribute__((always_inline)) {
+        uint32_t lo = 0, hi = kAdaptCells;
+#pragma unroll 1
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_run[mid] > x) hi = mid;
+            else lo = mid + 1;
+        }
+        return lo;
+    };
+    // Greedy cut for four bucket sizes at once: a bucket that starts at cell i takes cells while it
+    // stays within the size and within kAdaptMaxSpan cells (one cell at least), and the next one
+    // starts at the first occupied cell after it.
+    const uint32_t total = s_run[kAdaptCells - 1];
+    const uint32_t limits[kCandidates] = {total / 224u + 1u, total / 192u + 1u, total / 160u + 1u, total / 128u + 1u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t i = tid * 4u + q;
+        const uint32_t before = i ? s_run[i - 1] : 0u;
+#pragma unroll
+        for (int k = 0; k < kCandidates; ++k) {
+            uint32_t j = first_above(before + limits[k]);  // cells [i, j) hold at most the limit
+            j = j > i + 1u ? j : i + 1u;
+            j = j < i + kAdaptMaxSpan ? j : i + kAdaptMaxSpan;
+            j = j < kAdaptCells ? j : kAdaptCells;
+            s_nxt[k][i] = static_cast<unsigned short>(first_above(s_run[j - 1]));
+        }
+    }
+    __syncthreads();
+    if (tid < kCandidates) {
+        uint32_t i = first_above(0u), g = 0, mb = 0;
+#pragma unroll 1
+        while (i < kAdaptCells && g <= kHybBuckets) {
+            if (g < kHybBuckets) s_bfirst[tid][g] = static_cast<unsigned short>(i);
+            const uint32_t nx = s_nxt[tid][i];
+            const uint32_t cnt = s_run[nx - 1] - (i ? s_run[i - 1] : 0u);
+            mb = cnt > mb ? cnt : mb;
+            ++g;
+            i = nx;
+        }
+        s_groups[tid] = g;
+        s_maxb[tid] = mb;
+    }
+    __syncthreads();
+    int pick = -1;
+#pragma unroll
+    for (int k = kCandidates - 1; k >= 0; --k)
+        if (s_groups[k] <= kHybBuckets && s_maxb[k] <= adapt.bucket_max) pick = k;
+    if (pick < 0) return;  // uniform: the ordinary passes run (hdr->mode says so already)
+    const uint32_t buckets = s_groups[pick];
+    uint32_t atiles = 0, atincl = 0;
+    if (tid < kHybBuckets) {
+        const bool live = tid < buckets;
+        const uint32_t first = live ? s_bfirst[pick][tid] : kAdaptCells;
+        const uint32_t behind = tid + 1u < buckets ? s_bfirst[pick][tid + 1] : kAdaptCells;  // first cell of the next bucket
+        const uint32_t before = live && first ? s_run[first - 1] : 0u;
+        const uint32_t cnt = live ? s_run[behind - 1] - before : 0u;
+        // last occupied cell of the bucket: the first cell whose running sum reaches the bucket's end
+        uint32_t last = 0;
+        if (live) {
+            const uint32_t upto = s_run[behind - 1];
+            uint32_t lo = first, hi = behind - 1u;
+#pragma unroll 1
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_run[mid] >= upto) hi = mid;
+                else lo = mid + 1;
+            }
+            last = lo;
+        }
+        tb->bucket_start[tid] = live ? before : n;
+        tb->cell_first[tid] = first;
+        tb->cell_last[tid] = last;
+        const uint32_t from = tid == 0u ? 0u : first;  // the empty cells before the first bucket count as its own
+#pragma unroll 1
+        for (uint32_t cell = from; live && cell < behind; ++cell) tb->map_a[cell] = static_cast<uint8_t>(tid);
+        atiles = (cnt + tile_items - 1) / tile_items;
+        atincl = wave_inclusive_sum(atiles);
+        if (lane == 63) s_tsum[wave] = atincl;
+    }
+    __syncthreads();
+    if (tid < kHybBuckets) {
+        uint32_t off = atincl - atiles;
+        for (uint32_t w = 0; w < wave; ++w) off += s_tsum[w];
+        tb->first_tile[tid] = off;
+        if (tid == kHybBuckets - 1) {
+            tb->first_tile[kHybBuckets] = off + atiles;
+            tb->bucket_start[kHybBuckets] = n;
+            hdr->num_tiles_b = off + atiles;
+            hdr->adapt_buckets = buckets;
+            hdr->max_sub = 0;    // the counting kernel's workgroups enter the groups' sizes
+            hdr->big_pairs = 0;  // ... and the fine cells that are too large for a workgroup
+            hdr->mode = kHybAdapt;
+        }
+    }
+}
+
+// ---- the adaptive schedule: fine cells and groups of one bucket ------------------------------
+// Workgroup b, after pass A has gathered bucket b in `keys`:
+//   1. divides every occupied level-A cell of the bucket into a power of two of fine cells, about one
+//      per q pairs, with q the smallest of cap/512, cap/256, ... that keeps the bucket within 2^14 fine
+//      cells; a fine cell never straddles a multiple of 1 << low16_shift (the local sort takes 16 bits);
+//   2. counts the bucket's keys per fine cell (one LDS atomic per key; one add for a whole wave
+//      instruction whose lanes hold one fine cell);
+//   3. cuts the run of fine cells into groups greedily: a group takes fine cells while it stays
+//      within `cap` pairs and inside one 16-bit cell, one fine cell at least; where group g of the
+//      bucket starts is sub_start[256 b + g], which fine cells start a group is rank[b];
+//   4. enters fine cells of more than `cap` pairs in the list of oversized sub-buckets.
+// The last workgroup to finish turns that list into the tile table of the passes over it, or hands
+// the call to the ordinary passes (a bucket of more than 256 groups, too many oversized cells).
+__global__ __launch_bounds__(1024) void hybrid_adapt_count_kernel(const uint32_t* __restrict__ keys, HybridTables* tb,
+                                                                   HybridCleared* hc, const uint32_t n,
+                                                                   const uint32_t tile_items, const uint32_t cap,
+                                                                   const AdaptArgs adapt)
+{
+    constexpr uint32_t THREADS = 1024;
+    __shared__ uint32_t s_fine[kAdaptFine];              // pairs per fine cell, then their running sums
+    __shared__ unsigned short s_next[kAdaptFine];        // fine cell at which the group after the one starting here starts
+    __shared__ unsigned short s_bpos[kAdaptFine / 4 + 1];  // fine cells that begin a 16-bit cell, ascending
+    __shared__ uint32_t s_bound[kAdaptRankWords];        // the same as a bit map
+    __shared__ uint32_t s_bpre[kAdaptRankWords];         // set bits of s_bound in the words before
+    __shared__ uint32_t s_start[kAdaptRankWords];        // fine cells that start a group
+    __shared__ uint32_t s_entry[kAdaptMaxSpan];
+    __shared__ unsigned short s_gstart[kHybBuckets + 1];
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_total, s_ngroups, s_last, s_listed, s_nocc;
+    __shared__ uint32_t s_occ[kAdaptMaxSpan];  // occupied level-A cells of the bucket, ascending: first fine cell | cell << 16
+    HybridHeader* hdr = &hc->hdr;
+    if (hdr->mode != kHybAdapt) return;  // uniform
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t start = tb->bucket_start[b], end = tb->bucket_start[b + 1];
+    const bool live = b < hdr->adapt_buckets && end > start;  // uniform
+    uint32_t ngroups = 0;
+    if (live) {
+        const uint32_t first_cell = tb->cell_first[b], span = tb->cell_last[b] - first_cell + 1u;  // <= kAdaptMaxSpan
+        const uint32_t cell_shift = adapt.cell_shift;
+        const uint32_t min_log = cell_shift - adapt.low16_shift;  // a cell has at least this many fine cells (log2)
+        // ... and at most so many that a fine cell's number ends where the sorted bits begin (keys that
+        // differ below that are equal to a stable sort)
+        const uint32_t max_log = min(cell_shift - (adapt.low16_shift - 16u), kAdaptFineBits);
+        // ---- 1. fine cells per level-A cell ----
+        const uint32_t mine = tid < span ? tb->cell_count[first_cell + tid] : 0u;
+        uint32_t want_log = 0, want = 0;
+        for (uint32_t q = cap / 512u > 0u ? cap / 512u : 1u;; q *= 2u) {
+            want = 0;
+            if (mine != 0u) {
+                const uint32_t parts = (mine + q - 1u) / q;  // >= 1
+                want_log = 32u - static_cast<uint32_t>(__clz(parts - 1u | 0u));
+                if (parts <= 1u) want_log = 0;
+                want_log = want_log > min_log ? want_log : min_log;
+                want_log = want_log < max_log ? want_log : max_log;
+                want = 1u << want_log;
+            }
+            const uint32_t inc = wave_inclusive_sum(want);
+            __syncthreads();  // s_w is read below by every thread of the previous round
+            if (lane == 63) s_w[wave] = inc;
+            __syncthreads();
+            uint32_t all = 0, at = inc - want;
+            for (uint32_t w = 0; w < 16; ++w) {
+                all += s_w[w];
+                if (w < wave) at += s_w[w];
+            }
+            if (all <= kAdaptFine) {  // uniform
+                if (tid < span) {
+                    const uint32_t fine_shift = cell_shift - want_log;
+                    const uint32_t e = mine != 0u ? (at | (fine_shift << 16)) : 0u;
+                    s_entry[tid] = e;
+                    tb->cell_entry[first_cell + tid] = e;
+                }
+                if (tid == 0) s_total = all;
+                break;
+            }
+        }
+        // the occupied cells as a list (for the way back from a fine cell to its keys)
+        {
+            const uint32_t flag = tid < span && mine != 0u ? 1u : 0u;
+            const uint32_t inc = wave_inclusive_sum(flag);
+            __syncthreads();  // every thread has read s_w in the last round above
+            if (lane == 63) s_w[wave] = inc;
+            __syncthreads();
+            uint32_t at = inc - flag;
+            for (uint32_t w = 0; w < wave; ++w) at += s_w[w];
+            if (flag) s_occ[at] = (s_entry[tid] & 0xFFFFu) | (tid << 16);
+            if (tid == THREADS - 1u) s_nocc = at + flag;
+        }
+        for (uint32_t j = tid; j < kAdaptFine; j += THREADS) s_fine[j] = 0;
+        for (uint32_t j = tid; j < kAdaptRankWords; j += THREADS) {
+            s_bound[j] = 0;
+            s_start[j] = 0;
+        }
+        __syncthreads();
+        // fine cells that begin a 16-bit cell
+        if (tid < span && mine != 0u) {
+            const uint32_t base = s_entry[tid] & 0xFFFFu;
+            const uint32_t step = want >> min_log;  // fine cells per 16-bit cell
+            for (uint32_t j = 0; j < (1u << min_log); ++j) {
+                const uint32_t f = base + j * step;
+                atomicOr(&s_bound[f >> 5], 1u << (f & 31u));
+            }
+        }
+        // ---- 2. count ----
+        auto count = [&](uint32_t k) __attribute__((always_inline)) {
+            const uint32_t e = s_entry[((k >> cell_shift) & (kAdaptCells - 1u)) - first_cell];
+            const uint32_t f = (e & 0xFFFFu) + (__builtin_amdgcn_ubfe(k, 0u, cell_shift) >> (e >> 16));
+            const uint32_t f0 = __builtin_amdgcn_readfirstlane(f);
+            const unsigned long long same = __builtin_amdgcn_uicmp(f, f0, 32 /* == */);
+            const uint32_t group = static_cast<uint32_t>(__popcll(same));
+            if (group >= 8u && f == f0) {
+                if (lanes_below(static_cast<uint32_t>(same), static_cast<uint32_t>(same >> 32)) == 0u) atomicAdd(&s_fine[f0], group);
+            } else {
+                atomicAdd(&s_fine[f], 1u);
+            }
+        };
+        {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            uint32_t head_end = start, body_end = start;
+            if ((reinterpret_cast<uintptr_t>(keys) & 15u) == 0u) {
+                head_end = (start + 3u) & ~3u;
+                head_end = head_end < end ? head_end : end;
+                body_end = head_end + ((end - head_end) & ~3u);
+            } else {
+                head_end = end;
+                body_end = end;
+            }
+            for (uint32_t i = start + tid; i < head_end; i += THREADS) count(keys[i]);
+            const u32x4* __restrict__ vk = reinterpret_cast<const u32x4*>(keys);
+            const uint32_t v_end = body_end / 4u;
+            uint32_t v = head_end / 4u + tid;
+            for (; v + 7u * THREADS < v_end; v += 8u * THREADS) {
+                u32x4 x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = __builtin_nontemporal_load(vk + v + u * THREADS);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    count(x[u].x); count(x[u].y); count(x[u].z); count(x[u].w);
+                }
+            }
+            for (; v < v_end; v += THREADS) {
+                const u32x4 x = __builtin_nontemporal_load(vk + v);
+                count(x.x); count(x.y); count(x.z); count(x.w);
+            }
+            for (uint32_t i = body_end + tid; i < end; i += THREADS) count(keys[i]);
+        }
+        __syncthreads();
+        // ---- 3. groups ----
+        // running sums in place: thread t owns fine cells 16 t .. 16 t + 15
+        {
+            uint32_t v[16], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                v[q] = s_fine[tid * 16u + q];
+                sum += v[q];
+            }
+            const uint32_t inc = wave_inclusive_sum(sum);
+            if (lane == 63) s_w[wave] = inc;
+            __syncthreads();
+            uint32_t at = inc - sum;
+            for (uint32_t w = 0; w < wave; ++w) at += s_w[w];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                at += v[q];
+                s_fine[tid * 16u + q] = at;
+            }
+        }
+        __syncthreads();
+        // the 16-bit cells' first fine cells as a sorted list
+        if (tid < kAdaptRankWords) {
+            const uint32_t bits = s_bound[tid];
+            const uint32_t cnt = __popc(bits);
+            const uint32_t inc = wave_inclusive_sum(cnt);  // waves 0 to 7, all lanes
+            if (lane == 63) s_w[wave] = inc;
+            s_bpre[tid] = inc - cnt;
+        }
+        __syncthreads();
+        if (tid < kAdaptRankWords) {
+            uint32_t at = s_bpre[tid];
+            for (uint32_t w = 0; w < wave; ++w) at += s_w[w];
+            s_bpre[tid] = at;
+            uint32_t bits = s_bound[tid];
+            while (bits) {
+                const uint32_t bit = __builtin_ctz(bits);
+                bits &= bits - 1u;
+                s_bpos[at++] = static_cast<unsigned short>(tid * 32u + bit);
+            }
+        }
+        __syncthreads();
+        const uint32_t total_fine = s_total;
+        // first fine cell whose running sum exceeds x (kAdaptFine if none)
+        auto first_above = [&](uint32_t x) __attribute__((always_inline)) {
+            uint32_t lo = 0, hi = kAdaptFine;
+#pragma unroll 1
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_fine[mid] > x) hi = mid;
+                else lo = mid + 1;
+            }
+            return lo;
+        };
+        const uint32_t boundaries = s_bpre[kAdaptRankWords - 1] + __popc(s_bound[kAdaptRankWords - 1]);
+#pragma unroll 1
+        for (uint32_t q = 0; q < 16; ++q) {
+            const uint32_t f = tid * 16u + q;
+            if (f >= total_fine) {  // no pairs there: never visited
+                s_next[f] = static_cast<unsigned short>(kAdaptFine);
+                continue;
+            }
+            const uint32_t before = f ? s_fine[f - 1] : 0u;
+            uint32_t e = first_above(before + cap);  // fine cells [f, e) hold at most cap pairs
+            e = e > f + 1u ? e : f + 1u;
+            // ... and lie in one 16-bit cell: the next of those begins at the first listed fine cell after f
+            const uint32_t listed = s_bpre[f >> 5] + __popc(s_bound[f >> 5] & (0xFFFFFFFFu >> (31u - (f & 31u))));
+            const uint32_t wall = listed < boundaries ? s_bpos[listed] : kAdaptFine;
+            e = e < wall ? e : wall;
+            const uint32_t nx = first_above(s_fine[e - 1]);  // the first occupied fine cell behind the group
+            s_next[f] = static_cast<unsigned short>(nx);  // kAdaptFine: the group takes the bucket's last pair
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t f = first_above(0u), g = 0;
+#pragma unroll 1
+            while (f < kAdaptFine && g <= kHybBuckets) {
+                if (g < kHybBuckets) s_gstart[g] = static_cast<unsigned short>(f);
+                ++g;
+                f = s_next[f];
+            }
+            s_ngroups = f < kAdaptFine ? kHybBuckets + 1u : g;
+        }
+        __syncthreads();
+        ngroups = s_ngroups;
+    }
+    // ---- 4. tables ----
+    const bool fits = ngroups <= kHybBuckets;
+    // this bucket's part of the list of all groups
+    if (tid == 0) s_listed = live && fits ? atomicAdd(&hdr->adapt_groups, ngroups) : 0u;
+    __syncthreads();
+    if (tid < kHybBuckets) {
+        uint32_t at = end, cnt = 0;
+        if (live && fits && tid < ngroups) {
+            const uint32_t f = s_gstart[tid];
+            const uint32_t before = f ? s_fine[f - 1] : 0u;
+            const uint32_t upto = tid + 1u < ngroups ? s_fine[s_gstart[tid + 1] - 1u] : end - start;
+            at = start + before;
+            cnt = upto - before;
+            atomicOr(&s_start[f >> 5], 1u << (f & 31u));
+            if (cnt > cap) {
+                const uint32_t slot = atomicAdd(&hdr->num_big, 1u);
+                if (slot < kHybMaxBig) {
+                    tb->big_start[slot] = at;
+                    tb->big_end[slot] = at + cnt;
+                }
+                atomicAdd(&hdr->big_pairs, cnt);
+            }
+            atomicMax(&hdr->max_sub, cnt);
+            // The low key bits in which keys of the group can differ: from the first key of its first
+            // fine cell and the last key of its last occupied one (both in one 16-bit cell).
+            uint32_t span_bits = 16;
+            {
+                const uint32_t first_cell = tb->cell_first[b], cell_shift = adapt.cell_shift;
+                // last occupied fine cell: the first whose running sum reaches the group's end
+                uint32_t lo = f, hi = kAdaptFine - 1u;
+#pragma unroll 1
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_fine[mid] >= upto) hi = mid;
+                    else lo = mid + 1;
+                }
+                const uint32_t f_last = lo;
+                auto key_of = [&](uint32_t fine, bool last_key) __attribute__((always_inline)) {
+                    // the occupied cell with the largest first fine cell <= fine
+                    uint32_t a = 0, z = s_nocc - 1u;
+#pragma unroll 1
+                    while (a < z) {
+                        const uint32_t mid = (a + z + 1u) >> 1;
+                        if ((s_occ[mid] & 0xFFFFu) <= fine) a = mid;
+                        else z = mid - 1u;
+                    }
+                    const uint32_t cell = s_occ[a] >> 16, base = s_occ[a] & 0xFFFFu;
+                    const uint32_t fine_shift = s_entry[cell] >> 16;
+                    uint32_t k = ((first_cell + cell) << cell_shift) | ((fine - base) << fine_shift);
+                    if (last_key) k |= (1u << fine_shift) - 1u;
+                    return k;
+                };
+                const uint32_t differ = (key_of(f, false) ^ key_of(f_last, true)) & 0xFFFFu;
+                span_bits = 32u - static_cast<uint32_t>(__clz(differ));
+            }
+            tb->group_first[s_listed + tid] = at;  // at most 65536 in all: 256 buckets of at most 256
+            tb->group_pairs[s_listed + tid] = cnt | (span_bits << 27);  // cnt <= n / 4 < 2^27 wherever the schedule is offered
+        }
+        tb->sub_start[b * kHybBuckets + tid] = at;
+        tb->counts[b * kHybBuckets + tid] = cnt;
+        if (b == gridDim.x - 1u && tid == 0) tb->sub_start[kHybSubs] = n;
+    }
+    if (live && !fits && tid == 0) atomicOr(&hdr->adapt_fail, 1u);
+    __syncthreads();
+    if (live && tid < kAdaptRankWords) {
+        const uint32_t bits = s_start[tid];
+        const uint32_t cnt = __popc(bits);
+        const uint32_t inc = wave_inclusive_sum(cnt);
+        if (lane == 63) s_w[wave] = inc;
+        s_bpre[tid] = inc - cnt;
+    }
+    __syncthreads();
+    if (live && tid < kAdaptRankWords) {
+        uint32_t at = s_bpre[tid];
+        for (uint32_t w = 0; w < wave; ++w) at += s_w[w];
+        // digit of fine cell f = group starts at or before f, minus one
+        tb->rank[b][tid] = static_cast<unsigned long long>(s_start[tid]) | (static_cast<unsigned long long>(at - 1u) << 32);
+    }
+    // ---- the last workgroup closes the list of oversized fine cells ----
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&hdr->adapt_done, 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_last == 0u) return;  // uniform
+    __threadfence();
+    const uint32_t nbig = __hip_atomic_load(&hdr->num_big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t bigpairs = __hip_atomic_load(&hdr->big_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t failed = __hip_atomic_load(&hdr->adapt_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool good = failed == 0u && nbig <= kHybMaxBig && bigpairs <= n / 4u;
+    uint32_t tiles = 0, tincl = 0;
+    if (tid < kHybMaxBig) {
+        if (good && tid < nbig) {
+            const uint32_t cnt = __hip_atomic_load(&tb->big_end[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                                 __hip_atomic_load(&tb->big_start[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tiles = (cnt + tile_items - 1u) / tile_items;
+        }
+        tincl = wave_inclusive_sum(tiles);
+        if (lane == 63) s_w[wave] = tincl;
+    }
+    __syncthreads();
+    if (tid < kHybMaxBig) {
+        uint32_t off = tincl - tiles;
+        for (uint32_t w = 0; w < wave; ++w) off += s_w[w];
+        tb->big_first_tile[tid] = off;
+        if (tid == kHybMaxBig - 1u) {
+            tb->big_first_tile[kHybMaxBig] = off + tiles;
+            hdr->num_tiles_big = off + tiles;
+            if (!good) {
+                // the ordinary passes after all
+                hdr->num_tiles_b = 0;
+                hdr->num_big = 0;
+                hdr->mode = kHybFallback;
+            }
+        }
+    }
 }
 
 // ---- the oversized sub-buckets: digit counts and run positions -------------------------------
@@ -501,7 +996,7 @@ __global__ __launch_bounds__(1024) void hybrid_big_histogram_kernel(const uint32
 {
     __shared__ uint32_t s_h[2][256];
     __shared__ uint32_t s_seg[3];
-    if (hc->hdr.mode != kHybRun) return;  // uniform
+    if (hc->hdr.mode != kHybRun && hc->hdr.mode != kHybAdapt) return;  // uniform
     const uint32_t num_tiles = hc->hdr.num_tiles_big;
     const uint32_t tid = threadIdx.x;
     uint32_t ft0 = 0, ft1 = 0, bs0 = 0, bs1 = 0;
@@ -553,7 +1048,7 @@ __global__ __launch_bounds__(1024) void hybrid_big_histogram_kernel(const uint32
 __global__ __launch_bounds__(256) void hybrid_big_scan_kernel(const HybridTables* __restrict__ tb, HybridCleared* hc)
 {
     __shared__ uint32_t s_w[2][4];
-    if (hc->hdr.mode != kHybRun || blockIdx.x >= hc->hdr.num_big) return;  // uniform
+    if ((hc->hdr.mode != kHybRun && hc->hdr.mode != kHybAdapt) || blockIdx.x >= hc->hdr.num_big) return;  // uniform
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t seg = blockIdx.x;
     const uint32_t start = tb->big_start[seg];
@@ -598,9 +1093,13 @@ __global__ __launch_bounds__(256) void hybrid_big_scan_kernel(const HybridTables
 // on another stream feels).
 // One schedule's pass: every access to its description is an access to kernel arguments known at
 // compile time (a description picked at run time from two made every pass 15 to 30 % slower).
+// MAP == kMapRank (pass B of the adaptive schedule): the digit of a key is its group inside the
+// tile's bucket; the bucket's tables (`tables`) are copied to `s_entry` and `s_rank` tile by tile.
 template <bool SEG, bool PERSISTENT, int MAP, int THREADS, int KPT>
 __device__ __forceinline__ void gated_pass(const PassArgs& a, const SegmentTable& seg,
-                                           PassShared<8, THREADS, KPT, uint32_t, uint32_t>& sh, uint32_t (&s_seg)[4])
+                                           PassShared<8, THREADS, KPT, uint32_t, uint32_t>& sh, uint32_t (&s_seg)[4],
+                                           const HybridTables* __restrict__ tables = nullptr, uint32_t* s_entry = nullptr,
+                                           unsigned long long* s_rank = nullptr)
 {
     using S = PassShared<8, THREADS, KPT, uint32_t, uint32_t>;
     uint32_t tid = threadIdx.x;
@@ -647,6 +1146,19 @@ __device__ __forceinline__ void gated_pass(const PassArgs& a, const SegmentTable
             const uint32_t remaining = end - base;
             PassArgs b = a;
             b.digit_base = seg.digit_base + which * seg.digit_stride;
+            if constexpr (MAP == kMapRank) {
+                static_assert(SEG, "groups are numbered inside a bucket");
+                // the end-of-tile barrier below is behind every look-up of the previous tile's tables
+                const uint32_t first_cell = tables->cell_first[which];
+                const uint32_t cells = tables->cell_last[which] - first_cell + 1u;  // <= kAdaptMaxSpan
+                for (uint32_t j = tid; j < cells; j += THREADS) s_entry[j] = tables->cell_entry[first_cell + j];
+                for (uint32_t j = tid; j < kAdaptRankWords; j += THREADS) s_rank[j] = tables->rank[which][j];
+                __syncthreads();
+                b.digit_base = seg.digit_base + which * kHybBuckets;  // group g of bucket b is table entry 256 b + g
+                b.cell_entry = s_entry;
+                b.rank_words = s_rank;
+                b.cell_first = first_cell;
+            }
             if (remaining >= static_cast<uint32_t>(S::TILE))
                 process_tile<kModeOnesweep, kRankAtomic, MAP, true, uint32_t>(b, sh, tile, S::TILE, base, first, tid);
             else
@@ -671,18 +1183,42 @@ __device__ __forceinline__ void gated_pass(const PassArgs& a, const SegmentTable
 // ROLE names the launch for profilers and changes nothing else (kPassA, kPassB, kPassOversized,
 // kPassOrdinary): without it pass B and the usually idle passes over oversized sub-buckets would be
 // one kernel name, and a profiler's average duration of it would describe neither.
+// ADAPT: the launch also holds the same pass of the adaptive schedule (`adapt`; pass A by the byte
+// table adapt.digit_map, pass B over the same segment table by the groups of `tables`).
 enum PassRole { kPassA = 0, kPassB = 1, kPassOversized = 2, kPassOrdinary = 3 };
-template <bool SEG, bool DUAL, bool PERSISTENT, int MAP, int THREADS, int KPT, int ROLE>
+template <bool SEG, bool DUAL, bool PERSISTENT, int MAP, int THREADS, int KPT, int ROLE, bool ADAPT>
 __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs run, const SegmentTable seg,
-                                                                  const PassArgs other, const HybridHeader* __restrict__ hdr)
+                                                                  const PassArgs other, const HybridHeader* __restrict__ hdr,
+                                                                  const PassArgs adapt, const HybridTables* __restrict__ tables)
 {
     using S = PassShared<8, THREADS, KPT, uint32_t, uint32_t>;
     __shared__ S sh;
     __shared__ uint32_t s_seg[4];
     const uint32_t mode = hdr->mode;  // uniform
-    if (mode == kHybRun) {
+    // (the passes over oversized sub-buckets are the same in the adaptive schedule: its list holds fine cells)
+    if (mode == kHybRun || (ROLE == kPassOversized && mode == kHybAdapt)) {
         gated_pass<SEG, PERSISTENT, MAP, THREADS, KPT>(run, seg, sh, s_seg);
-    } else if constexpr (DUAL) {
+        return;
+    }
+    if constexpr (ADAPT) {
+        if (mode == kHybAdapt) {
+            if constexpr (SEG) {
+                __shared__ uint32_t s_entry[kAdaptMaxSpan];
+                __shared__ unsigned long long s_rank[kAdaptRankWords];
+                gated_pass<true, PERSISTENT, kMapRank, THREADS, KPT>(adapt, seg, sh, s_seg, tables, s_entry, s_rank);
+            } else {
+                // the first barrier of the pass orders these stores before any look-up
+                __shared__ __attribute__((aligned(4))) uint8_t s_map[kAdaptCells];
+                for (uint32_t j = threadIdx.x; j < kAdaptCells / 4; j += THREADS)
+                    reinterpret_cast<uint32_t*>(s_map)[j] = reinterpret_cast<const uint32_t*>(adapt.digit_map)[j];
+                PassArgs b = adapt;
+                b.digit_map = s_map;
+                gated_pass<false, PERSISTENT, kMapTable, THREADS, KPT>(b, seg, sh, s_seg);
+            }
+            return;
+        }
+    }
+    if constexpr (DUAL) {
         if (mode == kHybFallback) gated_pass<false, PERSISTENT, kMapNone, THREADS, KPT>(other, seg, sh, s_seg);
     }
 }
@@ -710,9 +1246,9 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
                                                                      uint32_t* __restrict__ vals,
                                                                      const HybridHeader* __restrict__ hdr,
                                                                      const HybridTables* __restrict__ tb,
-                                                                     const uint32_t shift, const uint32_t bits1,
-                                                                     const uint32_t bits2, const uint32_t num_subs,
-                                                                     const uint32_t key_shift)
+                                                                     const uint32_t run_shift, const uint32_t run_bits1,
+                                                                     const uint32_t run_bits2, const uint32_t run_subs,
+                                                                     const uint32_t run_key_shift, const uint32_t adapt_low16)
 {
     constexpr int WAVES = THREADS / 64;
     constexpr int RADIX = 256;
@@ -723,8 +1259,18 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLocalStageBytes];
     __shared__ uint32_t s_hist[2][WAVES][RADIX];
     __shared__ uint32_t s_wsum[2][4];
+    __shared__ uint32_t s_span[kLocalMaxPerGroup];  // adaptive groups: the low key bits in which a group's keys can differ
     __shared__ uint32_t s_first[kLocalMaxPerGroup], s_count[kLocalMaxPerGroup];
-    if (hdr->mode != kHybRun || blockIdx.x >= num_subs) return;  // uniform
+    // The adaptive schedule's groups: every entry of the table may be one, each lies in one 16-bit
+    // cell and is sorted on the two 8-bit digits below adapt_low16.  All of these are uniform.
+    const uint32_t mode = hdr->mode;
+    const bool adaptive = mode == kHybAdapt && adapt_low16 != 0u;
+    if (mode != kHybRun && !adaptive) return;
+    const uint32_t shift = adaptive ? adapt_low16 - 16u : run_shift;
+    const uint32_t bits1 = adaptive ? 8u : run_bits1, bits2 = adaptive ? 8u : run_bits2;
+    const uint32_t key_shift = adaptive ? adapt_low16 : run_key_shift;
+    const uint32_t num_subs = adaptive ? hdr->adapt_groups : run_subs;
+    if (blockIdx.x >= num_subs) return;
     uint2* const s_pair = reinterpret_cast<uint2*>(s_raw);
     uint32_t* const s_val = reinterpret_cast<uint32_t*>(s_raw);
     unsigned short* const s_key16 = reinterpret_cast<unsigned short*>(s_raw + CAP * 4);
@@ -754,20 +1300,31 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
     };
     // sorts the `cnt` pairs held in (key, val) into the stage; returns the key bits every key of the
     // sub-bucket has (COMPACT), which the write-out puts back
-    auto sort_in_stage = [&](auto ku_tag, uint32_t (&key)[KPT], uint32_t (&val)[KPT], const uint32_t cnt) __attribute__((always_inline)) -> uint32_t {
+    auto sort_in_stage = [&](auto ku_tag, uint32_t (&key)[KPT], uint32_t (&val)[KPT], const uint32_t cnt, const uint32_t span) __attribute__((always_inline)) -> uint32_t {
         constexpr int KU = decltype(ku_tag)::value;
         const uint32_t ku = (cnt + THREADS - 1) / THREADS;
         // item 0 of thread 0 always exists
         uint32_t high = 0;
         if constexpr (COMPACT) high = __builtin_amdgcn_readfirstlane(key[0]) >> key_shift << key_shift;
         PackedPos<KU> pos;  // ranks and slots are below 2^14: two to a register
+        // A group of the adaptive schedule spans whatever key range its fine cells do, often far less
+        // than 16 bits; counted on two fixed 8-bit digits the upper one would take few values, and the
+        // lanes of a wave would queue on few counters.  The bits in which the group's keys differ are
+        // divided between the two digits instead (the bits above them are the same for all keys):
+        // `span` low bits, from the counting kernel.
+        uint32_t dshift[2] = {shifts[0], shifts[1]}, dwidth[2] = {widths[0], widths[1]};
+        if (adaptive) {  // uniform; span: what the counting kernel found (uniform too)
+            dwidth[0] = span > 1u ? (span + 1u) / 2u : 1u;
+            dwidth[1] = span > 1u ? span - dwidth[0] : 1u;
+            dshift[1] = dshift[0] + dwidth[0];
+        }
         // The counters are zero: cleared before the first sub-bucket and then, each set, right
         // after its last use below; between that and the next use lie the barriers of the other
         // digit's phase.  The stage is not written before three barriers from here, behind which
         // every wave has left the previous write-out.
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const uint32_t sh = shifts[h], wd = widths[h];
+            const uint32_t sh = dshift[h], wd = dwidth[h];
             if (h == 1) {
                 // the order pass 1 left in LDS, read back slice by slice
 #pragma unroll
@@ -872,8 +1429,13 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
     const uint32_t mine = (num_subs - 1u - blockIdx.x) / gridDim.x + 1u;  // blockIdx.x < num_subs <= kHybSubs
     for (uint32_t j = tid; j < mine; j += THREADS) {
         const uint32_t which = blockIdx.x + j * gridDim.x;
-        const uint32_t first = tb->sub_start[which];
-        const uint32_t count = tb->sub_start[which + 1] - first;
+        // (the adaptive schedule's groups: from the list of all of them; the table's entries 256 b + g
+        // are used for about half of the g, which would leave half of the workgroups without work)
+        const uint32_t first = adaptive ? tb->group_first[which] : tb->sub_start[which];
+        // (pairs in the low 27 bits, the span above them)
+        const uint32_t packed_pairs = adaptive ? tb->group_pairs[which] : 0u;
+        const uint32_t count = adaptive ? packed_pairs & 0x7FFFFFFu : tb->sub_start[which + 1] - first;
+        s_span[j] = packed_pairs >> 27;
         s_first[j] = first;
         s_count[j] = count <= CAP ? count : 0u;
     }
@@ -885,7 +1447,7 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
     for (uint32_t j = 0; j < mine; ++j) {
         const uint32_t first = s_first[j], count = s_count[j];
         uint32_t high = 0;
-        if (count != 0u) high = sort_in_stage(all_items, key, val, count);
+        if (count != 0u) high = sort_in_stage(all_items, key, val, count, __builtin_amdgcn_readfirstlane(s_span[j]));
         if (j + 1 < mine && s_count[j + 1] != 0u) load_bucket(all_items, key, val, s_first[j + 1], s_count[j + 1]);
         if (count != 0u) write_out(first, count, high);
     }
@@ -924,9 +1486,15 @@ int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, ui
 }
 
 int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridCleared* hc, uint32_t n,
-                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, bool compact_ok, uint32_t* ghist,
-                       uint32_t begin_bit, uint32_t end_bit, uint32_t shift, uint32_t window_base, hipStream_t s)
+                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, bool compact_ok, uint32_t cap,
+                       const AdaptArgs& adapt, uint32_t* ghist, uint32_t begin_bit, uint32_t end_bit, uint32_t shift,
+                       uint32_t window_base, hipStream_t s)
 {
+    if (cap == 0 || cap > (compact_ok ? kHybLocalCapCompact : kHybLocalCapFull))
+        return fail(MRS_ERR_INVALID_ARGUMENT, "a workgroup of the local sort holds at most %u pairs", compact_ok ? kHybLocalCapCompact : kHybLocalCapFull);
+    if (adapt.offered && (adapt.msd_bits < kAdaptCellBits || adapt.msd_bits > 16u || adapt.cell_shift < adapt.low16_shift ||
+                          adapt.cell_shift - adapt.low16_shift > 4u || adapt.low16_shift < 16u))
+        return fail(MRS_ERR_UNSUPPORTED, "the adaptive schedule needs 28 to 32 sorted key bits");
     if (sub_bits < 6 || sub_bits > 8) return fail(MRS_ERR_UNSUPPORTED, "a bucket has 64 to 256 sub-buckets");
     if (shift > begin_bit + 16u || end_bit <= begin_bit + 24u || end_bit > begin_bit + 32u)
         return fail(MRS_ERR_UNSUPPORTED, "the ordinary passes are four digits of 8 bits, the exact table starts within the lowest two");
@@ -941,19 +1509,31 @@ int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, H
     hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(kHybPackedWords / 64), dim3(256), 0, s, packed, grid, hc->spill, tables->counts);
     MRS_CHECK_LAUNCH("hybrid_reduce_kernel");
     hipLaunchKernelGGL(hybrid_scan_kernel, dim3(1), dim3(1024), 0, s, tables, hc, n, tile_items, force_mode, sub_bits,
-                       compact_ok ? 1u : 0u, od);
+                       compact_ok ? 1u : 0u, cap, adapt, od);
     MRS_CHECK_LAUNCH("hybrid_scan_kernel");
     return MRS_OK;
 }
 
-template <bool SEG, bool DUAL, bool PERSISTENT, int MAP, int ROLE>
+int hybrid_launch_adapt_count(const uint32_t* keys, HybridTables* tables, HybridCleared* hc, uint32_t n, uint32_t tile_items,
+                              uint32_t cap, const AdaptArgs& adapt, hipStream_t s)
+{
+    const ProfilerRange range("Histogram calculation");  // src/main.rs:597
+    hipLaunchKernelGGL(hybrid_adapt_count_kernel, dim3(kHybBuckets), dim3(1024), 0, s, keys, tables, hc, n, tile_items, cap, adapt);
+    MRS_CHECK_LAUNCH("hybrid_adapt_count_kernel");
+    return MRS_OK;
+}
+
+template <bool SEG, bool DUAL, bool PERSISTENT, int MAP, int ROLE, bool ADAPT = false>
 static int launch_pass_shape(int threads, int kpt, const PassArgs& run, const SegmentTable& seg, const PassArgs& other,
-                             const HybridHeader* hdr, uint32_t grid, hipStream_t s)
+                             const HybridHeader* hdr, uint32_t grid, hipStream_t s, const PassArgs& adapt = PassArgs{},
+                             const HybridTables* tables = nullptr)
 {
     if (threads == 1024 && kpt == 32)
-        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 1024, 32, ROLE>), dim3(grid), dim3(1024), 0, s, run, seg, other, hdr);
+        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 1024, 32, ROLE, ADAPT>), dim3(grid), dim3(1024), 0, s, run, seg,
+                           other, hdr, adapt, tables);
     else if (threads == 512 && kpt == 8)
-        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 512, 8, ROLE>), dim3(grid), dim3(512), 0, s, run, seg, other, hdr);
+        hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 512, 8, ROLE, ADAPT>), dim3(grid), dim3(512), 0, s, run, seg,
+                           other, hdr, adapt, tables);
     else
         return fail(MRS_ERR_UNSUPPORTED, "no gated pass kernel for %d threads x %d keys per thread", threads, kpt);
     MRS_CHECK_LAUNCH("hybrid_pass_kernel");
@@ -961,11 +1541,15 @@ static int launch_pass_shape(int threads, int kpt, const PassArgs& run, const Se
 }
 
 int hybrid_launch_pass(int role, const PassArgs* run, const SegmentTable* seg, const PassArgs* other, bool persistent, bool windowed,
-                       int threads, int kpt, const HybridHeader* hdr, uint32_t grid, hipStream_t s)
+                       int threads, int kpt, const HybridHeader* hdr, uint32_t grid, hipStream_t s, const PassArgs* adapt,
+                       const HybridTables* tables)
 {
     if (!run && !other) return fail(MRS_ERR_INVALID_ARGUMENT, "a gated pass needs at least one description");
-    if ((run && run->wide_status) || (other && other->wide_status))
+    if ((run && run->wide_status) || (other && other->wide_status) || (adapt && adapt->wide_status))
         return fail(MRS_ERR_UNSUPPORTED, "gated passes use 32-bit tile status words");
+    if (adapt && (!tables || !persistent || windowed || role > kPassB))
+        return fail(MRS_ERR_UNSUPPORTED, "the adaptive schedule's passes are persistent launches of pass A and pass B");
+    const PassArgs& ad = adapt ? *adapt : PassArgs{};
     const ProfilerRange range("Indexing");  // src/main.rs:658
     if (grid == 0) grid = 1;
     // a `run` that is not given has no tiles, so it does nothing in its mode
@@ -978,8 +1562,9 @@ int hybrid_launch_pass(int role, const PassArgs* run, const SegmentTable* seg, c
         case kPassA:  // over the whole array
             if (segmented) break;
             if (persistent) {
-                if (windowed || !other) break;
-                return launch_pass_shape<false, true, true, kMapNone, kPassA>(threads, kpt, r, table, o, hdr, grid, s);
+                // the ordinary passes start one launch later (the adaptive schedule may hand over to them after its pass A)
+                if (windowed || other) break;
+                return launch_pass_shape<false, false, true, kMapNone, kPassA, true>(threads, kpt, r, table, o, hdr, grid, s, ad, tables);
             }
             if (other) break;
             return windowed ? launch_pass_shape<false, false, false, kMapWindow, kPassA>(threads, kpt, r, table, o, hdr, grid, s)
@@ -988,7 +1573,7 @@ int hybrid_launch_pass(int role, const PassArgs* run, const SegmentTable* seg, c
             if (!segmented) break;
             if (persistent) {
                 if (windowed || !other) break;
-                return launch_pass_shape<true, true, true, kMapNone, kPassB>(threads, kpt, r, table, o, hdr, grid, s);
+                return launch_pass_shape<true, true, true, kMapNone, kPassB, true>(threads, kpt, r, table, o, hdr, grid, s, ad, tables);
             }
             if (other) break;
             return windowed ? launch_pass_shape<true, false, false, kMapWindow, kPassB>(threads, kpt, r, table, o, hdr, grid, s)
@@ -1023,8 +1608,10 @@ int hybrid_launch_big_histogram(const uint32_t* keys, const HybridTables* tables
 
 int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,
                              uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, uint32_t key_shift,
-                             bool compact_ok, int grid, hipStream_t s)
+                             bool compact_ok, uint32_t adapt_low16, int grid, hipStream_t s)
 {
+    if (adapt_low16 != 0u && (adapt_low16 < 16u || (compact_ok && adapt_low16 != 16u)))
+        return fail(MRS_ERR_UNSUPPORTED, "the adaptive schedule's groups are sorted on 16 bits, staged in 6 bytes only if those are the low 16");
     if (num_subs == 0 || num_subs > kHybSubs) return fail(MRS_ERR_UNSUPPORTED, "at most 65536 sub-buckets");
     if (bits1 == 0 || bits1 > 8 || bits2 == 0 || bits2 > 8)
         return fail(MRS_ERR_UNSUPPORTED, "the local sort takes two digits of 1 to 8 bits");
@@ -1032,10 +1619,10 @@ int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader*
     const ProfilerRange range("Local sort");
     if (compact_ok)
         hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreads, kHybLocalKptCompact, true>), dim3(grid), dim3(kHybLocalThreads),
-                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift);
+                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift, adapt_low16);
     else
         hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreads, kHybLocalKptFull, false>), dim3(grid), dim3(kHybLocalThreads),
-                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift);
+                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift, adapt_low16);
     MRS_CHECK_LAUNCH("hybrid_local_sort_kernel");
     return MRS_OK;
 }

@@ -26,6 +26,27 @@
 //     those return at once.
 // Both schedules end on the same side (A: a -> b, B: b -> a, local and oversized: in place; four
 // passes: a again).
+//
+// Keys that crowd into few of the fixed sub-buckets (points on surfaces: most of the 65536 cells of
+// the leading 16 bits are empty and the occupied ones hold several workgroups' worth) can still be
+// sorted in three moves if the two scatters follow the keys' density instead of fixed bit fields
+// (kHybAdapt):
+//   plan    the exact table, added up over the 4096 cells of the leading 12 bits, is cut into at
+//           most 256 buckets of about n / 224 pairs each (whole cells, at most 256 cells from a
+//           bucket's first to its last): a 4096-entry byte table;
+//   pass A  scatters by that table;
+//   count   one workgroup per bucket reads its bucket and counts it on up to 2^14 "fine cells" (every
+//           occupied 12-bit cell of the bucket is divided into a power of two of them, more where
+//           it holds more pairs, never across a multiple of 2^16 key values), then cuts the run
+//           of fine cells into at most 256 groups of at most `cap` pairs: a bit per fine cell
+//           that starts a group, with a running count per word;
+//   pass B  scatters by the number of group starts at or before the key's fine cell (two LDS reads);
+//   local   a group lies inside one 16-bit cell, so the local sort takes it on its low 16 bits as
+//           it takes a sub-bucket; a fine cell that holds more than `cap` pairs alone is an
+//           oversized sub-bucket as above.
+// Tried only when the fixed sub-buckets were refused for their sizes.  If the count finds a
+// bucket that needs more than 256 groups (or too many oversized fine cells), the ordinary passes
+// run after all: they start one launch later than pass A for that reason.
 #ifndef MRS_HYBRID_HPP
 #define MRS_HYBRID_HPP
 
@@ -37,6 +58,13 @@ constexpr uint32_t kHybBuckets = 256;   // first level, at most: the top 8 of th
 constexpr uint32_t kHybSubs = 65536;    // second level, at most: the top 16
 constexpr uint32_t kHybRun = 1;         // HybridHeader::mode: the three-move schedule runs
 constexpr uint32_t kHybFallback = 2;    // the plan's least-significant-digit-first passes run
+constexpr uint32_t kHybAdapt = 3;       // the three-move schedule runs on buckets and groups cut to the keys' density
+constexpr uint32_t kAdaptCellBits = 12; // level-A cells: the leading 12 sorted bits
+constexpr uint32_t kAdaptCells = 1u << kAdaptCellBits;
+constexpr uint32_t kAdaptFineBits = 14; // fine cells per bucket, at most
+constexpr uint32_t kAdaptFine = 1u << kAdaptFineBits;
+constexpr uint32_t kAdaptRankWords = kAdaptFine / 32;
+constexpr uint32_t kAdaptMaxSpan = 256; // level-A cells from a bucket's first to its last, at most
 constexpr int kHybLocalThreads = 512;   // workgroup of the local sort
 constexpr int kHybLocalKptFull = 15;    // pairs per thread at most when a pair takes 8 bytes of LDS
 #ifndef MRS_LOCAL_KPT_COMPACT
@@ -58,7 +86,11 @@ struct HybridHeader {
     uint32_t num_tiles_big;  // tiles of the two passes over them
     uint32_t big_pairs;      // pairs they hold
     uint32_t high_vary;      // key bits at and above the sorted range differ between keys: no 6-byte staging
-    uint32_t pad[56];
+    uint32_t adapt_buckets;  // kHybAdapt: buckets pass A makes
+    uint32_t adapt_done;     // kHybAdapt: workgroups of the counting kernel that have finished
+    uint32_t adapt_fail;     // kHybAdapt: a bucket needs more than 256 groups
+    uint32_t adapt_groups;   // kHybAdapt: groups in all (diagnostic)
+    uint32_t pad[52];
 };
 static_assert(sizeof(HybridHeader) == 256, "the header takes one 256-byte slot of the cleared block");
 
@@ -82,6 +114,28 @@ struct HybridTables {
     uint32_t big_first_tile[kHybMaxBig + 4]; // first tile of oversized sub-bucket j; from [num_big] on: tiles in all
     uint32_t big_start[kHybMaxBig + 4];      // its first element
     uint32_t big_end[kHybMaxBig + 4];        // one past its last
+    // kHybAdapt only
+    uint8_t map_a[kAdaptCells];              // level-A cell -> bucket
+    uint32_t cell_count[kAdaptCells];        // pairs of level-A cell c
+    uint32_t cell_entry[kAdaptCells];        // first fine cell of level-A cell c in its bucket | (first key bit of a fine cell's number) << 16
+    uint32_t cell_first[kHybBuckets + 4];    // first occupied level-A cell of bucket b
+    uint32_t cell_last[kHybBuckets + 4];     // last one
+    // bucket b, word w: bit f % 32 = fine cell f = 32 w + f % 32 starts a group | (group starts in words before w, minus one) << 32
+    unsigned long long rank[kHybBuckets][kAdaptRankWords];
+    // the groups of all buckets in one list, in no particular order, for the local sort: first pair
+    // and pairs of group i < HybridHeader::adapt_groups
+    uint32_t group_first[kHybSubs];
+    uint32_t group_pairs[kHybSubs];
+};
+
+// What the adaptive schedule adds to a call (null plan pointers: not offered).
+struct AdaptArgs {
+    uint32_t offered;       // the plan can run it (host's conditions)
+    uint32_t force;         // test aid: skip the fixed sub-buckets
+    uint32_t cell_shift;    // first key bit of a level-A cell's number (end_bit - 12)
+    uint32_t low16_shift;   // groups never straddle a multiple of 1 << low16_shift (begin_bit + 16)
+    uint32_t bucket_max;    // pairs a bucket may hold
+    uint32_t msd_bits;      // bits of the exact table
 };
 
 // The segments a segmented chained-scan pass runs over (at most 256): segment s holds the
@@ -118,9 +172,16 @@ int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, ui
 // them) receives the exclusive digit prefix sums of the plan's four ordinary passes over
 // [begin_bit, end_bit): the two upper digits are sums over the exact table, which starts at `shift`
 // (within 16 bits of begin_bit) and, windowed, at sub-bucket `window_base`.
+// `cap`: pairs a workgroup of the local sort takes (test aid: less than it really holds).
 int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, HybridCleared* hc, uint32_t n,
-                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, bool compact_ok, uint32_t* ghist,
-                       uint32_t begin_bit, uint32_t end_bit, uint32_t shift, uint32_t window_base, hipStream_t s);
+                       uint32_t tile_items, uint32_t force_mode, uint32_t sub_bits, bool compact_ok, uint32_t cap,
+                       const AdaptArgs& adapt, uint32_t* ghist, uint32_t begin_bit, uint32_t end_bit, uint32_t shift,
+                       uint32_t window_base, hipStream_t s);
+// kHybAdapt: one workgroup per bucket counts the bucket (in `keys`, where pass A left it) on its
+// fine cells and cuts it into groups; the last workgroup to finish closes the list of oversized
+// fine cells or, if a bucket cannot be cut, hands the call to the ordinary passes.
+int hybrid_launch_adapt_count(const uint32_t* keys, HybridTables* tables, HybridCleared* hc, uint32_t n, uint32_t tile_items,
+                              uint32_t cap, const AdaptArgs& adapt, hipStream_t s);
 // One launch of the chained-scan pass for both schedules (either description may be null): `run`
 // is the pass of the three-move schedule (with `seg`: tiles and chains per segment, run->digit_base
 // and run->num_tiles ignored), taken if the device chose that schedule; `other` one of the plan's
@@ -130,8 +191,13 @@ int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, H
 // windowed: the digits are fields of (key >> shift) - window_base (PassArgs).
 // role: which launch of the schedule this is (0 pass A, 1 pass B, 2 a pass over the oversized
 // sub-buckets, 3 an ordinary pass on its own); it selects the kernel's name, nothing else.
+// `adapt`: null, or (roles 0 and 1, persistent) the same pass of the adaptive schedule, taken if the
+// device chose that one: pass A by the table adapt->digit_map over the bits from adapt->shift up,
+// pass B over the same segment table by the group numbers of `tables` (adapt->shift: first bit of a
+// level-A cell's number).
 int hybrid_launch_pass(int role, const PassArgs* run, const SegmentTable* seg, const PassArgs* other, bool persistent, bool windowed,
-                       int threads, int kpt, const HybridHeader* hdr, uint32_t grid, hipStream_t s);
+                       int threads, int kpt, const HybridHeader* hdr, uint32_t grid, hipStream_t s,
+                       const PassArgs* adapt = nullptr, const HybridTables* tables = nullptr);
 // Digit counts of the oversized sub-buckets on bits [shift, shift + bits1) and the bits2 above
 // them, and their scan into run positions (two launches).
 int hybrid_launch_big_histogram(const uint32_t* keys, const HybridTables* tables, HybridCleared* hc, uint32_t tile_items,
@@ -139,10 +205,11 @@ int hybrid_launch_big_histogram(const uint32_t* keys, const HybridTables* tables
 // Sorts every sub-bucket that fits a workgroup in place on bits [shift, shift + bits1 + bits2).
 // key_shift: key bits from here up are the same for all keys of a sub-bucket; compact_ok as for
 // hybrid_launch_scan (6-byte staging; the decision kernel has refused the schedule if the bits
-// above the sorted range vary).
+// above the sorted range vary).  adapt_low16: 0, or the adaptive schedule is offered and its groups
+// (65536 table entries) are sorted on the two 8-bit digits below bit adapt_low16.
 int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,
                              uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, uint32_t key_shift,
-                             bool compact_ok, int grid, hipStream_t s);
+                             bool compact_ok, uint32_t adapt_low16, int grid, hipStream_t s);
 
 }  // namespace mrs
 

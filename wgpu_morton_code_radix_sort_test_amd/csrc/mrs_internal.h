@@ -81,6 +81,13 @@ struct PassArgs {
     // of a sharded sort)
     uint32_t window_base;
     uint32_t window_low;
+    // kMapRank passes (the adaptive most-significant-digit-first schedule, mrs_hybrid.hpp): `shift` is
+    // the first bit of a level-A cell's number, cell_entry[cell - cell_first] = first fine cell of
+    // that cell | (first key bit of a fine cell's number) << 16, and the digit is the number of group
+    // starts at or before the key's fine cell, from rank_words (bit map with running counts)
+    const uint32_t* cell_entry;
+    const unsigned long long* rank_words;
+    uint32_t cell_first;
     // three-kernel: scanned block histogram, digit-major [radix][num_tiles]
     const uint32_t* scanned;
     // onesweep
@@ -137,9 +144,22 @@ struct TestAids {
     uint64_t hybrid_min_n = 0;         // 0 = the library's thresholds
     uint32_t hybrid_leading_bits = 0;  // 0 = chosen from n
     bool hybrid_force_fallback = false;
+    bool hybrid_force_adaptive = false;  // the fixed sub-buckets are passed over: buckets and groups cut to the keys
+    bool hybrid_no_adaptive = false;     // that schedule is not offered
+    uint32_t hybrid_capacity = 0;        // 0 = what a workgroup of the local sort holds; less: more groups, more oversized ones
     bool no_small_sort = false;
     bool no_pass_skip = false;
     bool wide_status = false;
+};
+
+// Tuning aids of profiling scripts, read from the environment once, when a context is created
+// (never inside a sort call): MRS_XCD_BLOCK, MRS_HIST_BLOCKS_PER_CU, MRS_HIST_PLAIN,
+// MRS_HIST_BANKED_PER_CU.
+struct Tuning {
+    int xcd_block = -1;                // tiles per die-aware ticket block; -1 = the default (8)
+    uint32_t hist_blocks_per_cu = 16;  // workgroups per compute unit of the plain digit histogram
+    bool hist_plain = false;           // the digit histogram without bank-spread counters (A/B aid)
+    uint32_t hist_banked_per_cu = 1;   // workgroups per compute unit of the bank-spread one
 };
 
 // A roctx range around the launches enqueued while the object lives, if ranges are switched on
@@ -174,6 +194,7 @@ struct mrs_context {
     void* static_scratch;
     // test and A/B aids (MRS_ATTR_TEST_*): copied into every plan at its creation
     mrs::TestAids aids;
+    mrs::Tuning tuning;
 };
 
 namespace mrs {
@@ -192,6 +213,7 @@ struct mrs_plan {
     uint32_t* hyb_packed;           // one packed 16-bit histogram per workgroup of the histogram kernel
     bool hyb_last;                  // the last sort call enqueued both schedules (hyb_cleared->hdr is its record)
     bool hyb_compact_ok;            // ... and its local sort could stage a pair in 6 bytes if the device agreed
+    uint32_t hyb_cap;               // ... and took a sub-bucket of at most this many pairs
     uint32_t radix_bits, radix, num_passes;
     uint32_t threads, kpt, tile_items;
     uint64_t max_tiles;

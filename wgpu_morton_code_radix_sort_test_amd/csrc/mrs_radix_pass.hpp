@@ -117,12 +117,20 @@ __device__ __forceinline__ uint32_t splitter_class(KeyT k, const KeyT* split, ui
 // behind every table lookup (the lookups of a thread's keys no longer overlap), so the host
 // selects it only for tables that do contain the mark: skewed inputs of the sharded sort.
 // kMapWindow: the digit is a bit field of (key >> shift) - window_base, see PassArgs.
-enum MapMode { kMapNone = 0, kMapTable = 1, kMapTableAndSplitters = 2, kMapWindow = 3 };
+// kMapRank: the digit is the number of marked fine cells at or before the key's, see PassArgs.
+enum MapMode { kMapNone = 0, kMapTable = 1, kMapTableAndSplitters = 2, kMapWindow = 3, kMapRank = 4 };
 
 template <int MAP, typename KeyT>
 __device__ __forceinline__ uint32_t key_digit(KeyT k, const PassArgs& a)
 {
     if constexpr (MAP == kMapWindow) return ((static_cast<uint32_t>(k >> a.shift) - a.window_base) >> a.window_low) & a.mask;
+    if constexpr (MAP == kMapRank) {
+        const uint32_t k32 = static_cast<uint32_t>(k);
+        const uint32_t e = a.cell_entry[((k32 >> a.shift) & a.mask) - a.cell_first];
+        const uint32_t f = (e & 0xFFFFu) + (__builtin_amdgcn_ubfe(k32, 0u, a.shift) >> (e >> 16));
+        const unsigned long long w = a.rank_words[f >> 5];
+        return static_cast<uint32_t>(w >> 32) + __popc(static_cast<uint32_t>(w) & (0xFFFFFFFFu >> (31u - (f & 31u))));
+    }
     uint32_t d = static_cast<uint32_t>(k >> a.shift) & a.mask;
     if constexpr (MAP == kMapTable || MAP == kMapTableAndSplitters) d = a.digit_map[d];
     if constexpr (MAP == kMapTableAndSplitters) {
