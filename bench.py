@@ -129,6 +129,9 @@ def load_modules():
     torch, mrs = _torch, _mrs
 
 
+SCHEDULE_NAMES = {0: "passes", 1: "msd", 2: "msd refused by the device", 3: "msd adaptive"}
+
+
 def make_input(ctx, n, seed, shape="uniform"):
     """points -> (keys, idx) on the device; returns the two tensors.  shape: "uniform" (the metric's
     input: points uniform in the unit cube); "cluster": the same with 5 % of the points inside a cube
@@ -482,7 +485,7 @@ def main():
             # every launch of one sort, mean of three: both schedules are enqueued, the one the
             # device did not choose returns at once (its launches are the sub-0.01 ms entries)
             extra["launch_ms"] = {lab: round(float(np.mean(v)) * (len(v) / 3.0), 4) for lab, v in launches.items()}
-            extra["schedule"] = {0: "passes", 1: "msd", 2: "msd refused by the device"}[schedule]
+            extra["schedule"] = SCHEDULE_NAMES[schedule]
             extra["largest_sub_bucket"] = largest
             local = float(np.mean(launches.get("msd_local_sort", [0.0]))) * 1e-3
             if local > 0:
@@ -490,8 +493,9 @@ def main():
             extra["moved_bytes_per_pair"] = 4 + 3 * 16  # what this schedule reads and writes; the 68 above is the metric's figure
             # the same plan type at the other sizes it serves and on other inputs: clustered points (a few
             # oversized sub-buckets, which two extra segmented passes sort where they lie), points on
-            # surfaces (most sub-buckets oversized: the device takes the four ordinary passes), equal keys,
-            # and 30-bit codes declared as 32-bit keys (three quarters of the leading buckets empty);
+            # surfaces (most fixed sub-buckets oversized: the device cuts buckets and groups to the keys'
+            # density, "msd adaptive"), equal keys (nothing to cut: the four ordinary passes), and 30-bit
+            # codes declared as 32-bit keys (three quarters of the leading buckets empty: adaptive);
             # library events, mean of 3 sorts after 1 warm-up; not part of `value`
             sweep = {}
             for label, log2m, eb, shape in () if args.no_extras else (("2^26", 26, 30, "uniform"), ("2^27", 27, 30, "uniform"), ("2^29", 29, 30, "uniform"),
@@ -517,9 +521,12 @@ def main():
                 which, biggest = p2.schedule()
                 over_subs, over_pairs, cap = p2.oversized()
                 sweep[label] = {"ms_per_sort": round(float(np.mean(ms2)), 4), "gkeys_per_s": m / (float(np.mean(ms2)) * 1e-3) / 1e9,
-                                "schedule": {0: "passes", 1: "msd", 2: "msd refused by the device"}[which],
+                                "schedule": SCHEDULE_NAMES[which],
                                 "largest_sub_bucket": biggest, "oversized_sub_buckets": over_subs, "oversized_pairs": over_pairs,
                                 "workgroup_capacity": cap, "verified": bool(verify_sorted(k2, i2, pk))}
+                if which == 3:
+                    sweep[label]["adaptive_buckets"], sweep[label]["adaptive_groups"] = p2.adaptive()
+                    sweep[label]["launch_ms"] = {lab: round(float(t), 4) for lab, t in p2.timings()}
                 p2.close()
                 del k2, i2, pk, pi, kb2, vb2
             extra["hybrid_other_inputs"] = sweep

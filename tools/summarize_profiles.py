@@ -59,9 +59,9 @@ def summarize_hybrid(args, n, library_rows):
         return {"read_bytes_per_launch": f * 1024.0 * factor, "write_bytes_per_launch": w * 1024.0 * cal_w,
                 "bytes_per_launch": f * 1024.0 * factor + w * 1024.0 * cal_w, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w}
 
-    # the last template argument of hybrid_pass_kernel names the launch: 0 pass A, 1 pass B
-    a = traffic("32, 0>(")
-    b = traffic("32, 1>(")
+    # the last but one template argument of hybrid_pass_kernel names the launch: 0 pass A, 1 pass B
+    a = traffic("32, 0, true>(")
+    b = traffic("32, 1, true>(")
     entry = {
         "kernel": "hybrid_pass_kernel (mean of pass A and pass B)",
         "n": n,

@@ -886,7 +886,8 @@ extern "C" int mrs_plan_get_schedule(mrs_plan* plan, void* stream, int32_t* sche
     if (!plan->hyb_last) return MRS_OK;
     HybridHeader h;
     MRS_HIP_TRY(hipMemcpy(&h, &plan->hyb_cleared->hdr, sizeof h, hipMemcpyDeviceToHost));
-    *schedule = h.mode == kHybRun ? MRS_SCHEDULE_MSD : (h.mode == kHybAdapt ? MRS_SCHEDULE_MSD_ADAPTIVE : MRS_SCHEDULE_MSD_REFUSED);
+    const uint32_t mode = hybrid_mode(h);
+    *schedule = mode == kHybRun ? MRS_SCHEDULE_MSD : (mode == kHybAdapt ? MRS_SCHEDULE_MSD_ADAPTIVE : MRS_SCHEDULE_MSD_REFUSED);
     if (largest_sub_bucket) *largest_sub_bucket = h.max_sub;
     return MRS_OK;
 }
@@ -904,8 +905,10 @@ extern "C" int mrs_plan_get_oversized(mrs_plan* plan, void* stream, uint32_t* su
     if (!plan->hyb_last) return MRS_OK;
     HybridHeader h;
     MRS_HIP_TRY(hipMemcpy(&h, &plan->hyb_cleared->hdr, sizeof h, hipMemcpyDeviceToHost));
-    if (sub_buckets) *sub_buckets = h.num_big;
-    if (pairs) *pairs = (h.mode == kHybRun || h.mode == kHybAdapt) ? h.big_pairs : 0;
+    const uint32_t mode = hybrid_mode(h);
+    const bool ran = mode == kHybRun || mode == kHybAdapt;
+    if (sub_buckets) *sub_buckets = ran ? h.num_big : 0;
+    if (pairs) *pairs = ran ? h.big_pairs : 0;
     if (capacity) *capacity = plan->hyb_cap;
     return MRS_OK;
 }
@@ -921,7 +924,7 @@ extern "C" int mrs_plan_get_adaptive(mrs_plan* plan, void* stream, uint32_t* buc
     if (!plan->hyb_last) return MRS_OK;
     HybridHeader h;
     MRS_HIP_TRY(hipMemcpy(&h, &plan->hyb_cleared->hdr, sizeof h, hipMemcpyDeviceToHost));
-    if (h.mode != kHybAdapt) return MRS_OK;
+    if (hybrid_mode(h) != kHybAdapt) return MRS_OK;
     if (buckets) *buckets = h.adapt_buckets;
     if (groups) *groups = h.adapt_groups;
     return MRS_OK;

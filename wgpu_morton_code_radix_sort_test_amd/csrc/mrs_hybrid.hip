@@ -630,6 +630,7 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
             hdr->adapt_buckets = buckets;
             hdr->max_sub = 0;    // the counting kernel's workgroups enter the groups' sizes
             hdr->big_pairs = 0;  // ... and the fine cells that are too large for a workgroup
+            hdr->big_limit = n / 4u;
             hdr->mode = kHybAdapt;
         }
     }
@@ -646,8 +647,9 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
 //      within `cap` pairs and inside one 16-bit cell, one fine cell at least; where group g of the
 //      bucket starts is sub_start[256 b + g], which fine cells start a group is rank[b];
 //   4. enters fine cells of more than `cap` pairs in the list of oversized sub-buckets.
-// The last workgroup to finish turns that list into the tile table of the passes over it, or hands
-// the call to the ordinary passes (a bucket of more than 256 groups, too many oversized cells).
+// A bucket of more than 256 groups raises hdr->adapt_fail; that, or too many or too full oversized
+// cells, hands the call to the ordinary passes (hybrid_mode).  The tile table of the passes over the
+// oversized cells is made by their histogram kernel.
 __global__ __launch_bounds__(1024) void hybrid_adapt_count_kernel(const uint32_t* __restrict__ keys, HybridTables* tb,
                                                                    HybridCleared* hc, const uint32_t n,
                                                                    const uint32_t tile_items, const uint32_t cap,
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(1024) void hybrid_adapt_count_kernel(const uint32_t
     __shared__ uint32_t s_entry[kAdaptMaxSpan];
     __shared__ unsigned short s_gstart[kHybBuckets + 1];
     __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_total, s_ngroups, s_last, s_listed, s_nocc;
+    __shared__ uint32_t s_total, s_ngroups, s_listed, s_nocc;
     __shared__ uint32_t s_occ[kAdaptMaxSpan];  // occupied level-A cells of the bucket, ascending: first fine cell | cell << 16
     HybridHeader* hdr = &hc->hdr;
     if (hdr->mode != kHybAdapt) return;  // uniform
@@ -947,64 +949,58 @@ __global__ __launch_bounds__(1024) void hybrid_adapt_count_kernel(const uint32_t
         // digit of fine cell f = group starts at or before f, minus one
         tb->rank[b][tid] = static_cast<unsigned long long>(s_start[tid]) | (static_cast<unsigned long long>(at - 1u) << 32);
     }
-    // ---- the last workgroup closes the list of oversized fine cells ----
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&hdr->adapt_done, 1u) == gridDim.x - 1u ? 1u : 0u;
-    __syncthreads();
-    if (s_last == 0u) return;  // uniform
-    __threadfence();
-    const uint32_t nbig = __hip_atomic_load(&hdr->num_big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t bigpairs = __hip_atomic_load(&hdr->big_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t failed = __hip_atomic_load(&hdr->adapt_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool good = failed == 0u && nbig <= kHybMaxBig && bigpairs <= n / 4u;
-    uint32_t tiles = 0, tincl = 0;
-    if (tid < kHybMaxBig) {
-        if (good && tid < nbig) {
-            const uint32_t cnt = __hip_atomic_load(&tb->big_end[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                                 __hip_atomic_load(&tb->big_start[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tiles = (cnt + tile_items - 1u) / tile_items;
-        }
-        tincl = wave_inclusive_sum(tiles);
-        if (lane == 63) s_w[wave] = tincl;
-    }
-    __syncthreads();
-    if (tid < kHybMaxBig) {
-        uint32_t off = tincl - tiles;
-        for (uint32_t w = 0; w < wave; ++w) off += s_w[w];
-        tb->big_first_tile[tid] = off;
-        if (tid == kHybMaxBig - 1u) {
-            tb->big_first_tile[kHybMaxBig] = off + tiles;
-            hdr->num_tiles_big = off + tiles;
-            if (!good) {
-                // the ordinary passes after all
-                hdr->num_tiles_b = 0;
-                hdr->num_big = 0;
-                hdr->mode = kHybFallback;
-            }
-        }
-    }
 }
 
 // ---- the oversized sub-buckets: digit counts and run positions -------------------------------
 // counts of the two local digits of every oversized sub-bucket, tile by tile of the passes that
 // will move them (a tile never straddles two of them)
-__global__ __launch_bounds__(1024) void hybrid_big_histogram_kernel(const uint32_t* __restrict__ keys,
-                                                                     const HybridTables* __restrict__ tb, HybridCleared* hc,
-                                                                     uint32_t tile_items, uint32_t shift, uint32_t bits1,
-                                                                     uint32_t bits2)
+__global__ __launch_bounds__(1024) void hybrid_big_histogram_kernel(const uint32_t* __restrict__ keys, HybridTables* tb,
+                                                                     HybridCleared* hc, uint32_t tile_items, uint32_t shift,
+                                                                     uint32_t bits1, uint32_t bits2)
 {
     __shared__ uint32_t s_h[2][256];
     __shared__ uint32_t s_seg[3];
-    if (hc->hdr.mode != kHybRun && hc->hdr.mode != kHybAdapt) return;  // uniform
-    const uint32_t num_tiles = hc->hdr.num_tiles_big;
+    __shared__ uint32_t s_ft[4];
+    const uint32_t mode = hybrid_mode(hc->hdr);  // uniform
+    if (mode != kHybRun && mode != kHybAdapt) return;
     const uint32_t tid = threadIdx.x;
+    uint32_t num_tiles = hc->hdr.num_tiles_big;
     uint32_t ft0 = 0, ft1 = 0, bs0 = 0, bs1 = 0;
-    if (tid < kHybMaxBig && num_tiles != 0u) {
-        ft0 = tb->big_first_tile[tid];
-        ft1 = tb->big_first_tile[tid + 1];
-        bs0 = tb->big_start[tid];
-        bs1 = tb->big_end[tid];
+    if (mode == kHybAdapt) {
+        // the adaptive schedule's list is in no order and has no tile table yet: every workgroup makes
+        // it for itself, the first one also for the two passes that follow
+        const uint32_t nbig = hc->hdr.num_big;  // <= kHybMaxBig in this mode
+        if (nbig == 0u) return;
+        uint32_t tiles = 0, incl = 0;
+        if (tid < kHybMaxBig) {  // waves 0 to 3, all lanes
+            if (tid < nbig) {
+                bs0 = tb->big_start[tid];
+                bs1 = tb->big_end[tid];
+                tiles = (bs1 - bs0 + tile_items - 1u) / tile_items;
+            }
+            incl = wave_inclusive_sum(tiles);
+            if ((tid & 63u) == 63u) s_ft[tid >> 6] = incl;
+        }
+        __syncthreads();
+        if (tid < kHybMaxBig) {
+            ft0 = incl - tiles;
+            for (uint32_t w = 0; w < (tid >> 6); ++w) ft0 += s_ft[w];
+            ft1 = ft0 + tiles;
+            if (blockIdx.x == 0) tb->big_first_tile[tid] = ft0;
+        }
+        num_tiles = s_ft[0] + s_ft[1] + s_ft[2] + s_ft[3];
+        if (blockIdx.x == 0 && tid == 0) {
+            tb->big_first_tile[kHybMaxBig] = num_tiles;
+            hc->hdr.num_tiles_big = num_tiles;
+        }
+    } else {
+        if (num_tiles == 0u) return;  // uniform: the usual case, and nothing below is needed
+        if (tid < kHybMaxBig) {
+            ft0 = tb->big_first_tile[tid];
+            ft1 = tb->big_first_tile[tid + 1];
+            bs0 = tb->big_start[tid];
+            bs1 = tb->big_end[tid];
+        }
     }
     for (uint32_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
         if (tid < 512) (&s_h[0][0])[tid] = 0;
@@ -1043,37 +1039,6 @@ __global__ __launch_bounds__(1024) void hybrid_big_histogram_kernel(const uint32
     }
 }
 
-// big_hist[j][h][d]: count -> position in the array of the run of digit d of oversized sub-bucket j
-// in the pass on digit h (both passes stay inside the sub-bucket's own range)
-__global__ __launch_bounds__(256) void hybrid_big_scan_kernel(const HybridTables* __restrict__ tb, HybridCleared* hc)
-{
-    __shared__ uint32_t s_w[2][4];
-    if ((hc->hdr.mode != kHybRun && hc->hdr.mode != kHybAdapt) || blockIdx.x >= hc->hdr.num_big) return;  // uniform
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t seg = blockIdx.x;
-    const uint32_t start = tb->big_start[seg];
-    uint32_t cnt[2], incl[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        cnt[h] = hc->big_hist[seg][h][tid];
-        incl[h] = cnt[h];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(incl[h], o);
-            if (lane >= static_cast<uint32_t>(o)) incl[h] += y;
-        }
-        if (lane == 63) s_w[h][wave] = incl[h];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        uint32_t off = incl[h] - cnt[h];
-        for (uint32_t w = 0; w < 4; ++w)
-            if (w < wave) off += s_w[h][w];
-        hc->big_hist[seg][h][tid] = start + off;
-    }
-}
-
 // ---- chained-scan passes that the device switches on or off --------------------------------
 // The digit pass of mrs_radix_pass.hpp behind a gate.  One launch serves both schedules, which
 // never run in the same call: if hdr->mode == kHybRun the pass `run` describes, over the whole
@@ -1095,11 +1060,14 @@ __global__ __launch_bounds__(256) void hybrid_big_scan_kernel(const HybridTables
 // compile time (a description picked at run time from two made every pass 15 to 30 % slower).
 // MAP == kMapRank (pass B of the adaptive schedule): the digit of a key is its group inside the
 // tile's bucket; the bucket's tables (`tables`) are copied to `s_entry` and `s_rank` tile by tile.
-template <bool SEG, bool PERSISTENT, int MAP, int THREADS, int KPT>
+// COUNTS: the segment table's digit_base holds the digit COUNTS of each segment, not yet the places
+// of the digits' runs (the passes over oversized sub-buckets: their histogram kernel leaves counts);
+// every tile turns its segment's 256 counts into places, in `s_bases`.
+template <bool SEG, bool PERSISTENT, int MAP, int THREADS, int KPT, bool COUNTS = false>
 __device__ __forceinline__ void gated_pass(const PassArgs& a, const SegmentTable& seg,
                                            PassShared<8, THREADS, KPT, uint32_t, uint32_t>& sh, uint32_t (&s_seg)[4],
                                            const HybridTables* __restrict__ tables = nullptr, uint32_t* s_entry = nullptr,
-                                           unsigned long long* s_rank = nullptr)
+                                           unsigned long long* s_rank = nullptr, uint32_t* s_bases = nullptr)
 {
     using S = PassShared<8, THREADS, KPT, uint32_t, uint32_t>;
     uint32_t tid = threadIdx.x;
@@ -1159,6 +1127,24 @@ __device__ __forceinline__ void gated_pass(const PassArgs& a, const SegmentTable
                 b.rank_words = s_rank;
                 b.cell_first = first_cell;
             }
+            if constexpr (COUNTS) {
+                static_assert(SEG && THREADS >= 256, "a thread per digit");
+                // s_bases[d] = start of the segment + counts of the digits below d; s_bases[256 ..] carry the waves' sums
+                uint32_t cnt = 0, inc = 0;
+                if (tid < 256u) {  // waves 0 to 3, all lanes
+                    cnt = b.digit_base[tid];
+                    inc = wave_inclusive_sum(cnt);
+                    if ((tid & 63u) == 63u) s_bases[256u + (tid >> 6)] = inc;
+                }
+                __syncthreads();
+                if (tid < 256u) {
+                    uint32_t off = start + inc - cnt;
+                    for (uint32_t w = 0; w < (tid >> 6); ++w) off += s_bases[256u + w];
+                    s_bases[tid] = off;
+                }
+                __syncthreads();
+                b.digit_base = s_bases;
+            }
             if (remaining >= static_cast<uint32_t>(S::TILE))
                 process_tile<kModeOnesweep, kRankAtomic, MAP, true, uint32_t>(b, sh, tile, S::TILE, base, first, tid);
             else
@@ -1194,9 +1180,16 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
     using S = PassShared<8, THREADS, KPT, uint32_t, uint32_t>;
     __shared__ S sh;
     __shared__ uint32_t s_seg[4];
-    const uint32_t mode = hdr->mode;  // uniform
+    const uint32_t mode = hybrid_mode(*hdr);  // uniform
     // (the passes over oversized sub-buckets are the same in the adaptive schedule: its list holds fine cells)
-    if (mode == kHybRun || (ROLE == kPassOversized && mode == kHybAdapt)) {
+    if constexpr (ROLE == kPassOversized) {
+        // (the same in the adaptive schedule: its list holds fine cells)
+        if (mode == kHybRun || mode == kHybAdapt) {
+            __shared__ uint32_t s_bases[256 + 4];
+            gated_pass<SEG, PERSISTENT, MAP, THREADS, KPT, true>(run, seg, sh, s_seg, nullptr, nullptr, nullptr, s_bases);
+            return;
+        }
+    } else if (mode == kHybRun) {
         gated_pass<SEG, PERSISTENT, MAP, THREADS, KPT>(run, seg, sh, s_seg);
         return;
     }
@@ -1263,7 +1256,7 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
     __shared__ uint32_t s_first[kLocalMaxPerGroup], s_count[kLocalMaxPerGroup];
     // The adaptive schedule's groups: every entry of the table may be one, each lies in one 16-bit
     // cell and is sorted on the two 8-bit digits below adapt_low16.  All of these are uniform.
-    const uint32_t mode = hdr->mode;
+    const uint32_t mode = hybrid_mode(*hdr);
     const bool adaptive = mode == kHybAdapt && adapt_low16 != 0u;
     if (mode != kHybRun && !adaptive) return;
     const uint32_t shift = adaptive ? adapt_low16 - 16u : run_shift;
@@ -1589,7 +1582,7 @@ int hybrid_launch_pass(int role, const PassArgs* run, const SegmentTable* seg, c
     return fail(MRS_ERR_UNSUPPORTED, "no gated pass kernel for this combination (role %d)", role);
 }
 
-int hybrid_launch_big_histogram(const uint32_t* keys, const HybridTables* tables, HybridCleared* hc, uint32_t tile_items,
+int hybrid_launch_big_histogram(const uint32_t* keys, HybridTables* tables, HybridCleared* hc, uint32_t tile_items,
                                 uint32_t shift, uint32_t bits1, uint32_t bits2, int grid, hipStream_t s)
 {
     if (bits1 == 0 || bits1 > 8 || bits2 == 0 || bits2 > 8)
@@ -1600,9 +1593,6 @@ int hybrid_launch_big_histogram(const uint32_t* keys, const HybridTables* tables
                            shift, bits1, bits2);
         MRS_CHECK_LAUNCH("hybrid_big_histogram_kernel");
     }
-    const ProfilerRange range("Small Prefix Sum");  // src/main.rs:625
-    hipLaunchKernelGGL(hybrid_big_scan_kernel, dim3(kHybMaxBig), dim3(256), 0, s, tables, hc);
-    MRS_CHECK_LAUNCH("hybrid_big_scan_kernel");
     return MRS_OK;
 }
 

@@ -87,11 +87,21 @@ struct HybridHeader {
     uint32_t big_pairs;      // pairs they hold
     uint32_t high_vary;      // key bits at and above the sorted range differ between keys: no 6-byte staging
     uint32_t adapt_buckets;  // kHybAdapt: buckets pass A makes
-    uint32_t adapt_done;     // kHybAdapt: workgroups of the counting kernel that have finished
+    uint32_t big_limit;      // kHybAdapt: pairs the oversized fine cells may hold together (n / 4)
     uint32_t adapt_fail;     // kHybAdapt: a bucket needs more than 256 groups
-    uint32_t adapt_groups;   // kHybAdapt: groups in all (diagnostic)
+    uint32_t adapt_groups;   // kHybAdapt: groups in all
     uint32_t pad[52];
 };
+
+// The schedule a call runs.  The decision kernel writes `mode`; the adaptive schedule can still
+// turn out not to work while its buckets are counted (a bucket that cannot be cut, too many or too
+// full oversized fine cells), which every later kernel, and the host, reads from what the counting
+// workgroups left in the header: no workgroup has to wait for the last of them.
+__host__ __device__ inline uint32_t hybrid_mode(const HybridHeader& h)
+{
+    if (h.mode == kHybAdapt && (h.adapt_fail != 0u || h.num_big > kHybMaxBig || h.big_pairs > h.big_limit)) return kHybFallback;
+    return h.mode;
+}
 static_assert(sizeof(HybridHeader) == 256, "the header takes one 256-byte slot of the cleared block");
 
 // Cleared by every sort call together with the header (it follows it in memory).
@@ -100,8 +110,7 @@ struct HybridCleared {
     // Counts the histogram workgroups moved out of their 16-bit counters, 32768 at a time, before
     // those could wrap: the exact count of sub-bucket i is spill[i] + the sum of the fields.
     uint32_t spill[kHybSubs];
-    // Oversized sub-bucket j: counts of its two local digits, then (hybrid_big_scan_kernel) the
-    // position of each digit's run in the array.
+    // Oversized sub-bucket j: counts of its two local digits.
     uint32_t big_hist[kHybMaxBig][2][256];
 };
 
@@ -178,8 +187,8 @@ int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, H
                        const AdaptArgs& adapt, uint32_t* ghist, uint32_t begin_bit, uint32_t end_bit, uint32_t shift,
                        uint32_t window_base, hipStream_t s);
 // kHybAdapt: one workgroup per bucket counts the bucket (in `keys`, where pass A left it) on its
-// fine cells and cuts it into groups; the last workgroup to finish closes the list of oversized
-// fine cells or, if a bucket cannot be cut, hands the call to the ordinary passes.
+// fine cells and cuts it into groups, enters oversized fine cells in their list and notes in the
+// header if its bucket cannot be cut (hybrid_mode then reads kHybFallback).
 int hybrid_launch_adapt_count(const uint32_t* keys, HybridTables* tables, HybridCleared* hc, uint32_t n, uint32_t tile_items,
                               uint32_t cap, const AdaptArgs& adapt, hipStream_t s);
 // One launch of the chained-scan pass for both schedules (either description may be null): `run`
@@ -199,8 +208,8 @@ int hybrid_launch_pass(int role, const PassArgs* run, const SegmentTable* seg, c
                        int threads, int kpt, const HybridHeader* hdr, uint32_t grid, hipStream_t s,
                        const PassArgs* adapt = nullptr, const HybridTables* tables = nullptr);
 // Digit counts of the oversized sub-buckets on bits [shift, shift + bits1) and the bits2 above
-// them, and their scan into run positions (two launches).
-int hybrid_launch_big_histogram(const uint32_t* keys, const HybridTables* tables, HybridCleared* hc, uint32_t tile_items,
+// them (the passes over them turn the counts into run positions tile by tile).
+int hybrid_launch_big_histogram(const uint32_t* keys, HybridTables* tables, HybridCleared* hc, uint32_t tile_items,
                                 uint32_t shift, uint32_t bits1, uint32_t bits2, int grid, hipStream_t s);
 // Sorts every sub-bucket that fits a workgroup in place on bits [shift, shift + bits1 + bits2).
 // key_shift: key bits from here up are the same for all keys of a sub-bucket; compact_ok as for
