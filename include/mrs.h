@@ -58,12 +58,17 @@ extern "C" {
                                    first lets the DEVICE decide sub-bucket by sub-bucket: one
                                    that does not fit a workgroup (equal keys, a cluster) is
                                    sorted where it lies by two more chained-scan passes on the
-                                   remaining bits; only when more than 256 sub-buckets are
-                                   oversized, or they hold over a quarter of the pairs, does
-                                   the device fall back to the four MRS_ALGO_ONESWEEP passes
-                                   (also n above about 2^29.1).  The result, its side and its
-                                   stability are those of MRS_ALGO_ONESWEEP either way.  Costs
-                                   about 35 MiB more temporary memory                           */
+                                   remaining bits.  When more than 256 sub-buckets are oversized,
+                                   or they hold over a quarter of the pairs (codes of points on
+                                   surfaces, which is what triangle centroids are,
+                                   src/main.rs:114-173), the same three moves follow tables the
+                                   device cuts to the keys' density instead of fixed bit fields
+                                   (28..32 sorted bits from bit 0, up to about 2^28.5 pairs); only
+                                   keys that cannot be cut that way either (nearly all equal)
+                                   fall back to the four MRS_ALGO_ONESWEEP passes (also n above
+                                   about 2^29.1).  The result, its side and its stability are
+                                   those of MRS_ALGO_ONESWEEP every time.  Costs about 45 MiB
+                                   more temporary memory                                        */
 
 /* byte sizes of the reference buffer elements */
 #define MRS_MORTON_UNIFORMS_BYTES 51248 /* MortonCodeConstants, morton_code.wgsl:19-26 */
@@ -222,7 +227,8 @@ int mrs_hybrid_split_for(uint64_t n, int32_t begin_bit, int32_t end_bit, const u
 #define MRS_SCHEDULE_MSD_ADAPTIVE 3
 int mrs_plan_get_schedule(mrs_plan* plan, void* stream, int32_t* schedule, uint32_t* largest_sub_bucket);
 /* Synchronises `stream`.  For the most recent sort call on an MRS_ALGO_HYBRID plan that ran
- * MRS_SCHEDULE_MSD: how many sub-buckets did not fit a workgroup of the local sort and were sorted
+ * MRS_SCHEDULE_MSD or MRS_SCHEDULE_MSD_ADAPTIVE: how many sub-buckets (adaptive: single fine cells
+ * of a bucket, that is runs of nearly equal keys) did not fit a workgroup of the local sort and were sorted
  * where they lay by the two extra chained-scan passes (*sub_buckets, at most 256), how many pairs
  * they held (*pairs, at most n / 4), and what a workgroup held in that call (*capacity: 10240 pairs
  * when a pair could be staged in 6 bytes, its low 16 key bits and its payload, else 7680).  Zeros
@@ -245,8 +251,10 @@ int mrs_plan_get_adaptive(mrs_plan* plan, void* stream, uint32_t* buckets, uint3
  * duration in milliseconds and a label of at most 31 characters
  * ("memset", "global_histogram", "histogram_scan", "onesweep_pass", "block_histogram", "scan",
  * "scatter", "small_sort", "gather"; MRS_ALGO_HYBRID plans: "msd_histogram", "msd_scan",
- * "fallback_histogram", "msd_pass_a", "msd_pass_b", "msd_local_sort", "msd_oversized_histogram",
- * "msd_oversized_pass", "fallback_pass").  labels_out holds cap * 32 bytes. */
+ * "fallback_histogram", "msd_pass_a", "msd_adaptive_count", "msd_pass_b", "msd_local_sort",
+ * "msd_oversized_histogram", "msd_oversized_pass", "fallback_pass"; one launch carries the same
+ * pass of every schedule the device can choose, so e.g. "msd_pass_b" is also the first ordinary
+ * pass of a refused call).  labels_out holds cap * 32 bytes. */
 int mrs_plan_set_timing(mrs_plan* plan, int enable);
 int mrs_plan_get_timings(mrs_plan* plan, int cap, float* ms_out, char* labels_out, int* count_out);
 
