@@ -4,12 +4,15 @@
     python bench.py --gpus N --steps K --warmup W
 
 One step = one sort of the resident batch: 2^28 (30-bit Morton key, u32 index)
-pairs per GPU through an MRS_ALGO_HYBRID plan over key bits [0, 30): a 16-bit
-histogram, two chained-scan scatters by the top two 8-bit digits and a sort of
-the 65536 sub-buckets inside LDS (three moves of every pair; the device falls
-back to four 8-bit passes on keys that are not spread well enough, which the
-line reports as `schedule`).  `--algo onesweep` times the four least-significant-
-digit-first passes over all 32 key bits instead.  Inputs are synthetic: points from the library's counter-based generator (seed 7) encoded to
+pairs per GPU through an MRS_ALGO_HYBRID plan over key bits [0, 30): an exact
+histogram of the leading 15 bits, two chained-scan scatters by those bits and a
+sort of the 32768 sub-buckets inside LDS (three moves of every pair; sub-buckets
+that do not fit a workgroup get two extra passes of their own, keys that crowd
+into few sub-buckets are scattered by tables the device cuts to their density,
+and keys that cannot be cut either take four 8-bit passes: the line reports what
+the device chose as `schedule`, and `hybrid_other_inputs` times such inputs).
+`--algo onesweep` times the four least-significant-digit-first passes over all
+32 key bits instead.  Inputs are synthetic: points from the library's counter-based generator (seed 7) encoded to
 Morton keys on the GPU before the timed region.  Every step sorts a FRESH
 unsorted buffer from a pool built beforehand (sorting mutates its input, and
 re-sorting sorted data would be a different workload), so the timed region
