@@ -170,3 +170,47 @@ def test_not_offered_when_switched_off(ctx, oracle, mrs, small, aids):
     rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 30)
     assert schedule == mrs.SortPlan.SCHEDULE_MSD_REFUSED
     assert np.array_equal(ko, rk) and np.array_equal(vo, rv)
+
+
+def test_fuzz(ctx, oracle, mrs, small):
+    """Seeded random sizes, widths, capacities and key shapes with the adaptive form offered (and, in
+    half of the cases, forced): whatever the device decides, the result is the stable sort."""
+    import os
+
+    seed = int(os.environ.get("MRS_FUZZ_SEED", "20261112"))
+    rng = np.random.RandomState(seed)
+    seen = set()
+    for case in range(int(os.environ.get("MRS_FUZZ_CASES", "30"))):
+        n = int(rng.choice([rng.randint(4097, 20000), rng.randint(20000, 200000), rng.randint(200000, 900000)]))
+        end = int(rng.randint(28, 33))
+        shape = ["surface", "thick", "random", "morton30", "few_distinct", "dup", "two_cells"][rng.randint(7)]
+        if shape in ("surface", "thick"):
+            keys = _surface_codes(n, seed=case, shell=float(rng.rand()), thickness=0.0 if shape == "surface" else 0.01)
+        elif shape == "dup":
+            keys = make_keys(oracle, n, 1, "morton30", seed=case) & np.uint32(~0x3FF & 0xFFFFFFFF)
+        elif shape == "two_cells":  # everything in two cells of the leading 12 bits, one of them a single key value
+            keys = (make_keys(oracle, n, 1, "random", seed=case) & np.uint32(0x3FFFF)) | np.uint32(0x155 << 18)
+            keys[: n // 3] = np.uint32(0x2AA << 18) | np.uint32(12345)
+        else:
+            keys = make_keys(oracle, n, 1, shape, seed=case)
+        if end < 32 and shape not in ("surface", "thick", "two_cells", "dup", "morton30"):
+            keys = keys & np.uint32((1 << end) - 1)  # nothing above the sorted range: 6-byte staging stays possible
+        if end > 30 and shape in ("surface", "thick", "dup", "morton30", "two_cells") and rng.randint(2):
+            keys = keys << np.uint32(end - 30)  # use the declared width
+        capacity = int(rng.choice([0, 0, int(rng.randint(40, 400)), int(rng.randint(400, 4000))]))
+        forced = bool(rng.randint(2))
+        ctx.set_attribute(ctx.ATTR_TEST_HYBRID_CAPACITY, capacity)
+        ctx.set_attribute(ctx.ATTR_TEST_HYBRID_FORCE_ADAPTIVE, 1 if forced else 0)
+        try:
+            vals = make_vals(oracle, n, 1)
+            ko, vo, in_b, schedule, largest, over = _sort(ctx, mrs, keys, vals, n, end, twice=bool(rng.randint(2)))
+        finally:
+            ctx.set_attribute(ctx.ATTR_TEST_HYBRID_CAPACITY, 0)
+            ctx.set_attribute(ctx.ATTR_TEST_HYBRID_FORCE_ADAPTIVE, 0)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, end)
+        what = (case, n, end, shape, capacity, forced, schedule, largest, over)
+        seen.add(schedule)
+        assert not in_b, what
+        assert np.array_equal(ko, rk), what
+        assert np.array_equal(vo, rv), what
+    assert mrs.SortPlan.SCHEDULE_MSD_ADAPTIVE in seen

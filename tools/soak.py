@@ -58,7 +58,8 @@ def main():
     ap.add_argument("--tile-items", type=int, default=0)
     ap.add_argument("--hybrid", action="store_true",
                     help="an MRS_ALGO_HYBRID plan over key bits [0, 30): two of three inputs are spread keys (the "
-                         "three-move schedule), the third makes the device refuse it; sizes vary from sort to sort")
+                         "three-move schedule) or points on surfaces (its adaptive form), the third makes the device refuse it; "
+                         "sizes vary from sort to sort")
     ap.add_argument("--u64", action="store_true",
                     help="64-bit keys + index; the high word is masked differently every iteration, so passes "
                          "with a constant digit (left out on the device) come and go")
@@ -89,6 +90,18 @@ def main():
             idx = torch.arange(n, dtype=torch.int32, device=ctx.device)
         else:
             xyz = ctx.generate_points(100 + it, n)
+            if args.hybrid and it % 5 == 1:
+                # points on a sphere shell and three planes: the fixed sub-buckets crowd and the device
+                # cuts its own (the adaptive form of the schedule)
+                half = n // 2
+                d = xyz[:half] - 0.5
+                d /= d.norm(dim=1, keepdim=True).clamp_min(1e-6)
+                xyz[:half] = 0.5 + (0.45 if it % 2 else 0.3) * d
+                third = (n - half) // 3
+                xyz[half:half + third, 0] = 0.3
+                xyz[half + third:half + 2 * third, 1] = 0.55
+                xyz[half + 2 * third:, 2] = 0.8
+                del d
             keys, idx = ctx.morton_encode30(xyz, [0, 0, 0], [1, 1, 1])
             del xyz
         ref = keys.clone()
@@ -111,7 +124,7 @@ def main():
         if it % 10 == 9:
             print(f"{it + 1} sorts checked, {bad} bad", flush=True)
     if args.hybrid:
-        print("schedules (0 passes, 1 three moves, 2 refused by the device):", schedules)
+        print("schedules (0 passes, 1 three moves, 2 refused by the device, 3 three moves on buckets and groups cut to the keys):", schedules)
     print("SOAK", "FAILED" if bad else "ok", f"({args.iters} sorts of up to 2^{args.log2n} pairs)")
     sys.exit(1 if bad else 0)
 
