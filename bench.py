@@ -256,8 +256,10 @@ def rocprim_context(keys, vals, end_bit, want_k, want_v, sorts=3):
 
 def c4_leg(ctx, log2n=30, sorts=3, context=False):
     """The 2^30-pair configuration (and, with log2n=31, the whole 2^31-pair job of the 8-GPU
-    configuration on one GPU): 64-bit tile status words and offsets; HIP events of the library
-    around every launch.  Returns None when the device is short of memory."""
+    configuration on one GPU); HIP events of the library around every launch.  2^30 pairs take an
+    MRS_ALGO_HYBRID plan over key bits [0, 30) (three moves; the four passes over all 32 bits, with
+    64-bit tile status words and offsets, are timed beside it as `four_passes`), 2^31 the four
+    passes.  Returns None when the device is short of memory."""
     n = 1 << log2n
     free_b, _ = torch.cuda.mem_get_info()
     if free_b < 44 * n:  # points 12 B + pairs 8 B x 3 (input, pristine copy, ping-pong) + slack
@@ -267,28 +269,48 @@ def c4_leg(ctx, log2n=30, sorts=3, context=False):
     del xyz
     pk, pi = keys.clone(), idx.clone()
     kb, vb = torch.empty_like(keys), torch.empty_like(idx)
-    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, algo=mrs.ALGO_ONESWEEP)
-    plan.set_timing(True)
-    totals, passes = [], []
-    for j in range(sorts + 1):
-        keys.copy_(pk)
-        idx.copy_(pi)
-        plan.sort_pairs(keys, idx, kb, vb)
-        tm = plan.timings()
-        if j:  # the first sort warms up
-            totals.append(sum(ms for _, ms in tm))
-            passes = [ms for lab, ms in tm if lab == "onesweep_pass"]
-    plan.check()
+    def timed(plan, labels):
+        plan.set_timing(True)
+        totals, passes, launches = [], [], {}
+        for j in range(sorts + 1):
+            keys.copy_(pk)
+            idx.copy_(pi)
+            plan.sort_pairs(keys, idx, kb, vb)
+            tm = plan.timings()
+            if j:  # the first sort warms up
+                totals.append(sum(ms for _, ms in tm))
+                passes = [ms for lab, ms in tm if lab in labels]
+                launches = {}
+                for lab, ms in tm:
+                    launches[lab] = round(launches.get(lab, 0.0) + ms, 4)
+        plan.check()
+        return float(np.mean(totals)), passes, launches
+
+    three_moves = log2n == 30
+    four = None
+    if three_moves:
+        plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, algo=mrs.ALGO_ONESWEEP)
+        ms4, passes4, _ = timed(plan, ("onesweep_pass",))
+        four = {"ms_per_sort": round(ms4, 4), "gkeys_per_s": n / (ms4 * 1e-3) / 1e9,
+                "per_pass_ms": [round(float(x), 4) for x in passes4], "verified": bool(verify_sorted(keys, idx, pk)),
+                "algo": "onesweep: four passes over all 32 key bits, 64-bit tile status words"}
+        plan.close()
+        plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, end_bit=30, algo=mrs.ALGO_HYBRID)
+        ms, passes, launches = timed(plan, ("msd_pass_a", "msd_pass_b"))
+        schedule = plan.schedule()[0]
+    else:
+        plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, algo=mrs.ALGO_ONESWEEP)
+        ms, passes, launches = timed(plan, ("onesweep_pass",))
+        schedule = 0
     ok = verify_sorted(keys, idx, pk)
     plan.close()
     del kb, vb
     rp = None
     if context:
         try:
-            rp = rocprim_context(pk, pi, 32, keys, idx, sorts=2)
+            rp = rocprim_context(pk, pi, 30 if three_moves else 32, keys, idx, sorts=2)
         except Exception as exc:  # a context number: the leg stands without it
             rp = {"error": str(exc)}
-    ms = float(np.mean(totals))
     return {
         "rocprim_context": rp,
         "pairs": n,
@@ -297,9 +319,14 @@ def c4_leg(ctx, log2n=30, sorts=3, context=False):
         "frac_68B": SORT_BYTES_PER_PAIR * n / (ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
         "per_pass_ms": [round(float(x), 4) for x in passes],
         "pass_frac_16B": PASS_BYTES_PER_PAIR * n / (float(np.mean(passes)) * 1e-3) / HBM_PEAK_BYTES_PER_S,
-        "tile_status_words": "64-bit",
-        "algo": "onesweep: four passes over all 32 key bits (the three-move schedule needs sub-buckets of at most 10240 pairs "
-                "among at most 65536, n / 65536 here is above that)",
+        "schedule": SCHEDULE_NAMES[schedule],
+        "launch_ms": launches,
+        "four_passes": four,
+        "algo": ("hybrid over key bits [0, 30): exact 16-bit histogram, two chained-scan scatters, 65536 sub-buckets of about 16384 pairs "
+                 "sorted in LDS by workgroups of 1024 threads (20480 pairs each); 32-bit tile status words")
+                if three_moves else
+                ("onesweep: four passes over all 32 key bits, 64-bit tile status words (the three-move schedule needs sub-buckets of at "
+                 "most 20480 pairs among at most 65536, n / 65536 here is above that)"),
         "timing": f"HIP events recorded by the library around every launch of {sorts} sorts after 1 warm-up",
         "verified": bool(ok),
     }

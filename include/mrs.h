@@ -49,7 +49,7 @@ extern "C" {
 /* pass algorithm */
 #define MRS_ALGO_THREE_KERNEL 0 /* histogram -> prefix sum -> scatter, as src/main.rs:594-665 */
 #define MRS_ALGO_ONESWEEP 1     /* one histogram kernel + one chained-scan kernel per digit   */
-#define MRS_ALGO_HYBRID 2       /* (u32 key, 4-byte payload) pairs on 25..32 key bits, n < 2^30:
+#define MRS_ALGO_HYBRID 2       /* (u32 key, 4-byte payload) pairs on 25..32 key bits, n <= 2^30:
                                    three moves of every pair instead of the four of
                                    src/main.rs:594 -- two chained-scan scatters by the top two
                                    digits (the second one bucket by bucket), then every one of
@@ -65,8 +65,8 @@ extern "C" {
                                    device cuts to the keys' density instead of fixed bit fields
                                    (28..32 sorted bits from bit 0, up to about 2^28.5 pairs); only
                                    keys that cannot be cut that way either (nearly all equal)
-                                   fall back to the four MRS_ALGO_ONESWEEP passes (also n above
-                                   about 2^29.1).  The result, its side and its stability are
+                                   fall back to the four MRS_ALGO_ONESWEEP passes (also more than
+                                   2^29.1 pairs where over 16 key bits lie below the leading 16).  The result, its side and its stability are
                                    those of MRS_ALGO_ONESWEEP every time.  Costs about 45 MiB
                                    more temporary memory                                        */
 
@@ -157,6 +157,9 @@ int mrs_context_destroy(mrs_context* ctx);
                                                  buckets and groups to the keys (MRS_SCHEDULE_MSD_ADAPTIVE)
                                                  wherever that schedule is offered                       */
 #define MRS_ATTR_TEST_HYBRID_NO_ADAPTIVE 12   /* 1: that schedule is not offered                          */
+#define MRS_ATTR_TEST_HYBRID_BIG_LOCAL 14     /* 1: the local sort runs its workgroups of 1024 threads
+                                                 (20480 pairs each, what inputs of 2^29.1 to 2^30 pairs
+                                                 take) at any size where a pair is staged in 6 bytes     */
 #define MRS_ATTR_TEST_HYBRID_CAPACITY 13      /* pairs a workgroup of the local sort is taken to hold
                                                  (0: what it holds, 7680 or 10240): smaller values make
                                                  oversized sub-buckets and many groups out of small inputs */

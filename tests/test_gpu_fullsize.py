@@ -70,7 +70,7 @@ def test_full_size_sort_properties(ctx, mrs, log2n, algo_name, bits):
 
 
 @pytest.mark.parametrize("log2n,end_bit,want", [(28, 30, "msd"), (28, 32, "adaptive"), (27, 30, "msd"), (26, 30, "msd"),
-                                                (26, 32, "passes"), (29, 30, "msd")])
+                                                (26, 32, "passes"), (29, 30, "msd"), (30, 30, "msd"), (30, 32, "refused")])
 def test_full_size_hybrid_plan_equals_four_passes(ctx, mrs, log2n, end_bit, want):
     """MRS_ALGO_HYBRID plans at the sizes they exist for, against the four-pass plan on the same
     input, pair for pair (a stable sort has one answer), plus the size-independent properties.
@@ -78,8 +78,13 @@ def test_full_size_hybrid_plan_equals_four_passes(ctx, mrs, log2n, end_bit, want
     the rest too full: the device cuts buckets and groups to the keys instead, and the result is
     still that of the four passes; 2^26 pairs of 32-bit keys are
     below the size the three-move schedule pays for: the host does not enqueue it; 2^29 pairs leave
-    sub-buckets of 8192 pairs, which fit a workgroup that stages a pair in 6 bytes."""
+    sub-buckets of 8192 pairs, which fit a workgroup that stages a pair in 6 bytes; 2^30 pairs leave
+    sub-buckets of 16384, which fit the local sort's workgroups of 1024 threads (the ordinary passes a
+    refusal falls back to use 64-bit tile status words there: 30-bit codes declared as 32-bit keys)."""
     n = 1 << log2n
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 48 * n:
+        pytest.skip("not enough device memory for this size")
     xyz = ctx.generate_points(23, n)
     keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
     del xyz

@@ -193,6 +193,33 @@ def test_mix_of_empty_normal_and_oversized_sub_buckets(ctx, oracle, mrs, small_i
         assert np.array_equal(vo, rv), "payload"
 
 
+@pytest.mark.parametrize("end,leading,shift", [(32, 16, 16), (30, 16, 14), (30, 15, 15)])
+def test_workgroups_of_1024_threads(ctx, oracle, mrs, small_inputs_take_the_schedule, aids, end, leading, shift):
+    """The local sort that inputs of 2^29.1 to 2^30 pairs take (one workgroup of 1024 threads per compute
+    unit, 20480 pairs each), switched on at a size the checker can follow: sub-buckets that are
+    empty, small, beyond what the 512-thread workgroups hold, exactly full, and one pair more than
+    full (that one is sorted by the two extra passes); twice on one plan, also with made-up indices."""
+    aids(ctx.ATTR_TEST_HYBRID_LEADING_BITS, leading)
+    aids(ctx.ATTR_TEST_HYBRID_BIG_LOCAL, 1)
+    cap = 20480
+    sizes = [cap, cap + 1, 10241, 15000, 20479, 1, 4097]
+    kinds = ["random", "random", "few", "random", "equal", "random", "random"]
+    n = 6 * (cap + 1) + sum(sizes) + 54321
+    keys = _keys_with_sub_buckets(oracle, n, shift, sizes, kinds, 0, end, seed=end + leading)
+    if end < 32:
+        keys &= np.uint32((1 << end) - 1)
+    for indexed in (False, True):
+        vals = np.arange(n, dtype=np.uint32) if indexed else make_vals(oracle, n, 1)
+        info = []
+        ko, vo, in_b, schedule, largest = _sort_with_plan(ctx, mrs, keys, vals, n, 0, end, oversized=info, twice=True,
+                                                          indexed=indexed)
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, end)
+        assert schedule == mrs.SortPlan.SCHEDULE_MSD and not in_b
+        assert largest == cap + 1 and info == [1, cap + 1, cap], (largest, info)
+        assert np.array_equal(ko, rk), "keys"
+        assert np.array_equal(vo, rv), "payload"
+
+
 def test_one_sub_bucket_with_most_of_the_pairs_is_refused(ctx, oracle, mrs, small_inputs_take_the_schedule):
     """90 % of the pairs in one sub-bucket: the extra passes would move most pairs four times, so the
     device takes the plan's ordinary passes; the result is the same stable sort."""
@@ -363,7 +390,7 @@ def test_unsupported_shapes_are_refused(ctx, mrs):
         with pytest.raises(MrsError):
             mrs.SortPlan(ctx, 100000, **args)
     with pytest.raises(MrsError):
-        mrs.SortPlan(ctx, 1 << 30, key_words=1, payload_bytes=4, digit_bits=8, algo=mrs.ALGO_HYBRID)
+        mrs.SortPlan(ctx, (1 << 30) + 1, key_words=1, payload_bytes=4, digit_bits=8, algo=mrs.ALGO_HYBRID)
 
 
 def test_fuzz(ctx, oracle, mrs, small_inputs_take_the_schedule):

@@ -195,7 +195,7 @@ def test_hybrid_split_of_the_whole_key_space():
     for begin, end in ((0, 30), (0, 32), (3, 29), (0, 25), (7, 32), (0, 31)):
         width = end - begin
         for n in (1, 4097, 1 << 22, (1 << 26) - 1, 1 << 26, (1 << 26) + 1, 3 << 25, 1 << 27, (1 << 27) + 12345, 1 << 28,
-                  (1 << 28) + (1 << 26), 6500 << 16, (6500 << 16) + 65536, 1 << 29, (1 << 30) - 1):
+                  (1 << 28) + (1 << 26), 6500 << 16, (6500 << 16) + 65536, 1 << 29, (1 << 30) - 1, 1 << 30):
             rc, s = _hybrid_split(lib, n, begin, end)
             assert rc == _lib.MRS_OK
             # the local sort takes two digits of at most 8 bits, the scatters 7 or 8 bits each
@@ -205,16 +205,18 @@ def test_hybrid_split_of_the_whole_key_space():
             # a workgroup holds 10240 pairs when the sub-bucket's own bits start at bit 16 or below
             # (a pair is then staged in 6 bytes of LDS), else 7680; evenly spread keys must leave a
             # sixth of that free (the few sub-buckets that do not fit get two extra passes)
+            # ... and 20480 in the workgroups of 1024 threads that larger inputs take where 6-byte staging applies
             cap = 10240 if s.shift <= 16 else 7680
-            assert bool(s.offered) == (min_n <= n and (n >> s.leading_bits) <= cap * 5 // 6), (begin, end, n)
+            largest = 20480 if s.shift <= 16 else 7680
+            assert bool(s.offered) == (min_n <= n and (n >> s.leading_bits) <= largest * 5 // 6), (begin, end, n)
             if s.offered:
-                assert n / (1 << s.leading_bits) <= cap * 5 // 6 + 1
+                assert n / (1 << s.leading_bits) <= largest * 5 // 6 + 1
                 # and no finer split than needed: the next coarser one would fill a workgroup beyond four fifths
                 if s.leading_bits > max(14, width - 16):
                     coarser_cap = 10240 if s.shift + 1 <= 16 else 7680
                     assert n >> (s.leading_bits - 1) > coarser_cap * 4 // 5
     assert _hybrid_split(lib, 1 << 26, 0, 24)[0] == _lib.MRS_ERR_UNSUPPORTED
-    assert _hybrid_split(lib, 1 << 30, 0, 30)[0] == _lib.MRS_ERR_UNSUPPORTED
+    assert _hybrid_split(lib, (1 << 30) + 1, 0, 30)[0] == _lib.MRS_ERR_UNSUPPORTED
     assert _hybrid_split(lib, 0, 0, 30)[0] == _lib.MRS_ERR_UNSUPPORTED
 
 

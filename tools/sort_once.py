@@ -58,6 +58,10 @@ def main():
     ap.add_argument("--leading-bits", type=int, default=0, help="MRS_ATTR_TEST_HYBRID_LEADING_BITS (14..16; 0 = the library's choice)")
     ap.add_argument("--adaptive", default="auto", choices=["auto", "force", "off"],
                     help="hybrid plans: the cut that follows the keys' density is the device's choice, forced, or not offered")
+    ap.add_argument("--pad-bytes", type=int, default=-1,
+                    help="32-bit keys + index: the four buffers (keys, index, and the ping-pong pair) are carved out of "
+                         "one allocation, each this many bytes further from a multiple of the buffer size than the one "
+                         "before (-1: four allocations of their own)")
     ap.add_argument("--hi-mask", type=lambda v: int(v, 0), default=0xFFFFFFFF,
                     help="64-bit keys: mask applied to the high word (short codes have constant high bytes)")
     ap.add_argument("--gather", action="store_true",
@@ -77,8 +81,14 @@ def main():
                         end_bit=args.end_bit or None)
     plan.set_timing(True)
     kw, pw = args.key_words, args.payload_bytes // 4
-    kb = torch.empty(n * kw, dtype=torch.int32, device=ctx.device)
-    vb = torch.empty(max(1, n * pw), dtype=torch.int32, device=ctx.device)
+    arena = None
+    if args.pad_bytes >= 0 and kw == 1 and pw == 1 and not args.gather:
+        step = n + args.pad_bytes // 4
+        arena = torch.empty(4 * step, dtype=torch.int32, device=ctx.device)
+        kb, vb = arena[2 * step:2 * step + n], arena[3 * step:3 * step + n]
+    else:
+        kb = torch.empty(n * kw, dtype=torch.int32, device=ctx.device)
+        vb = torch.empty(max(1, n * pw), dtype=torch.int32, device=ctx.device)
     rows = []
     for it in range(args.iters):
         if args.dist in ("morton30", "cluster5", "shell", "planes", "dup64", "surface"):
@@ -102,6 +112,13 @@ def main():
                 keys.fill_(12345)
             idx = torch.arange(n, dtype=torch.int32, device=ctx.device)
         vals = idx if pw == 1 else (ctx.generate_u32(5, it, n * pw) if pw else None)
+        if arena is not None:
+            step = n + args.pad_bytes // 4
+            arena[0:n].copy_(keys)
+            arena[step:step + n].copy_(vals)
+            del keys, idx, vals
+            keys, vals = arena[0:n], arena[step:step + n]
+            idx = vals
         if args.gather:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

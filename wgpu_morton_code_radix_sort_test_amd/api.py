@@ -78,6 +78,7 @@ class Context:
     ATTR_TEST_HYBRID_FORCE_ADAPTIVE = 11
     ATTR_TEST_HYBRID_NO_ADAPTIVE = 12
     ATTR_TEST_HYBRID_CAPACITY = 13
+    ATTR_TEST_HYBRID_BIG_LOCAL = 14
     NOALLOC_MAX_N = 1 << 26
 
     def attribute(self, which):

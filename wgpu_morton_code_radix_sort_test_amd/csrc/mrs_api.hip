@@ -585,6 +585,7 @@ extern "C" int mrs_context_get_attribute(const mrs_context* ctx, int attribute, 
         case MRS_ATTR_TEST_HYBRID_FORCE_ADAPTIVE: *value = ctx->aids.hybrid_force_adaptive ? 1 : 0; return MRS_OK;
         case MRS_ATTR_TEST_HYBRID_NO_ADAPTIVE: *value = ctx->aids.hybrid_no_adaptive ? 1 : 0; return MRS_OK;
         case MRS_ATTR_TEST_HYBRID_CAPACITY: *value = ctx->aids.hybrid_capacity; return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_BIG_LOCAL: *value = ctx->aids.hybrid_big_local ? 1 : 0; return MRS_OK;
         default: return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_get_attribute: unknown attribute %d", attribute);
     }
 }
@@ -624,6 +625,7 @@ extern "C" int mrs_context_set_attribute(mrs_context* ctx, int attribute, int64_
         case MRS_ATTR_TEST_WIDE_STATUS: ctx->aids.wide_status = value != 0; return MRS_OK;
         case MRS_ATTR_TEST_HYBRID_FORCE_ADAPTIVE: ctx->aids.hybrid_force_adaptive = value != 0; return MRS_OK;
         case MRS_ATTR_TEST_HYBRID_NO_ADAPTIVE: ctx->aids.hybrid_no_adaptive = value != 0; return MRS_OK;
+        case MRS_ATTR_TEST_HYBRID_BIG_LOCAL: ctx->aids.hybrid_big_local = value != 0; return MRS_OK;
         case MRS_ATTR_TEST_HYBRID_CAPACITY:
             if (value < 0 || value > kHybLocalCapCompact)
                 return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_context_set_attribute: capacity must be 0 (default) or 1..%u", kHybLocalCapCompact);
@@ -657,10 +659,10 @@ static int fill_plan(mrs_plan* p, mrs_context* ctx, const mrs_plan_desc* d, cons
         // with more temporary memory and a device-side choice between two schedules.
         const int width = d->end_bit - d->begin_bit;
         if (d->key_words != 1 || d->payload_bytes != 4 || d->digit_bits != 8 || width < 25 || width > 32 ||
-            d->n >= (1ull << 30) || (d->tile_items != 0 && d->tile_items != 4096 && d->tile_items != 32768))
+            d->n > (1ull << 30) || (d->tile_items != 0 && d->tile_items != 4096 && d->tile_items != 32768))
             return fail(MRS_ERR_UNSUPPORTED,
                         "%s: MRS_ALGO_HYBRID sorts (u32 key, 4-byte payload) pairs on 25 to 32 key bits with 8-bit digits, "
-                        "n < 2^30, tile_items 0, 4096 or 32768",
+                        "n <= 2^30, tile_items 0, 4096 or 32768",
                         who);
         resolved.algo = MRS_ALGO_ONESWEEP;
         // ranking by returning LDS atomics is all the gated kernels are built for; a device that
@@ -984,6 +986,7 @@ static uint32_t hybrid_msd_bits(uint32_t end, uint32_t width, uint32_t n, const 
 struct HybridSplit {
     uint32_t msd_bits, shift, base;
     bool windowed;
+    bool big;  // the local sort's workgroups of 1024 threads (20480 pairs): 2^29.1 to 2^30 evenly spread pairs
 };
 
 // The split for keys known to lie in [lo, hi]: with 14, 15 or 16 bits for passes A and B, the
@@ -1002,7 +1005,7 @@ static bool hybrid_window_split(uint32_t begin, uint32_t n, uint64_t lo, uint64_
         const uint64_t subs = (hi >> shift) - (lo >> shift) + 1;
         const uint64_t limit = bits < 16 ? hybrid_local_cap(shift) * 4ull / 5 : hybrid_local_cap(shift) * 5ull / 6;
         if (shift - begin <= 16 && n / subs <= limit) {
-            *out = HybridSplit{bits, shift, static_cast<uint32_t>(lo >> shift), true};
+            *out = HybridSplit{bits, shift, static_cast<uint32_t>(lo >> shift), true, false};
             return true;
         }
     }
@@ -1022,11 +1025,18 @@ static bool hybrid_choose_split(uint32_t begin, uint32_t end, uint64_t n, const 
     }
     // Evenly spread keys must leave sub-buckets a workgroup can hold with a sixth to spare (the few
     // that do not fit are sorted by two extra passes, but not most of them): up to about 2^28.7
-    // pairs with 8-byte staging, 2^29.1 with 6-byte staging.  Beyond that the device would refuse,
-    // so it is not asked.
+    // pairs with 8-byte staging, 2^29.1 with 6-byte staging and two workgroups of 512 threads per
+    // compute unit, 2^30 with 6-byte staging and one workgroup of 1024 (which holds twice as much but
+    // has no neighbour to fill its waits: 1.2 ms per 2^28 pairs instead of 0.98).  Beyond that the
+    // device would refuse, so it is not asked.  aids.hybrid_big_local: test aid, the large workgroups
+    // at any size.
     const uint32_t msd_bits = hybrid_msd_bits(end, end - begin, n32, aids);
-    *split = HybridSplit{msd_bits, end - msd_bits, 0u, false};
-    return n >= hybrid_min_n(end - begin, aids) && (n >> msd_bits) <= hybrid_local_cap(split->shift) * 5ull / 6;
+    *split = HybridSplit{msd_bits, end - msd_bits, 0u, false, false};
+    if (n < hybrid_min_n(end - begin, aids)) return false;
+    const uint64_t per_sub = n >> msd_bits;
+    if (per_sub <= hybrid_local_cap(split->shift) * 5ull / 6 && !(aids.hybrid_big_local && split->shift <= 16u)) return true;
+    split->big = split->shift <= 16u && per_sub <= kHybLocalCapBig * 5ull / 6;
+    return split->big;
 }
 
 // The schedule of an MRS_ALGO_HYBRID plan (mrs_hybrid.hpp): both pass sequences are enqueued and the
@@ -1058,7 +1068,7 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     const bool compact_ok = split.shift <= 16u;
 #endif
     plan->hyb_compact_ok = compact_ok;
-    uint32_t cap = compact_ok ? kHybLocalCapCompact : kHybLocalCapFull;
+    uint32_t cap = split.big ? kHybLocalCapBig : (compact_ok ? kHybLocalCapCompact : kHybLocalCapFull);
     if (plan->aids.hybrid_capacity != 0 && plan->aids.hybrid_capacity < cap) cap = plan->aids.hybrid_capacity;  // test aid
     plan->hyb_cap = cap;
     // Passes loop over tiles with one workgroup per compute unit where that costs nothing (same time
@@ -1071,7 +1081,7 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     // which lies inside one cell of the 16 bits above begin_bit, can be staged in 6 bytes per pair and
     // the 4096 cells of the leading 12 bits are made of such cells: 28 to 32 sorted bits from bit 0.
     AdaptArgs adapt{};
-    adapt.offered = loop && compact_ok && begin_bit == 0 && end_bit >= 28 && !plan->aids.hybrid_no_adaptive;
+    adapt.offered = loop && compact_ok && !split.big && begin_bit == 0 && end_bit >= 28 && !plan->aids.hybrid_no_adaptive;
     adapt.force = adapt.offered && plan->aids.hybrid_force_adaptive;
     adapt.cell_shift = end_bit - kAdaptCellBits;
     adapt.low16_shift = begin_bit + 16u;
@@ -1119,6 +1129,7 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
         f.xcd_block = xcd_block;
         f.error_flag = plan->error_flag;
         f.index_payload = indexed && pass == 0;
+        f.wide_status = plan->status_word_bytes == 8;  // plans of 2^30 pairs: a digit of theirs can count 2^30 keys
     }
     PassArgs a{};
     a.n = n32;
@@ -1194,7 +1205,8 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     // ... of the sub-buckets that fit a workgroup: inside LDS, in place
     if (int rc = hybrid_launch_local_sort(static_cast<uint32_t*>(keys_a), static_cast<uint32_t*>(vals_a), hdr, plan->hyb_tables,
                                           begin_bit, bits1, bits2, 1u << msd_bits, split.shift, compact_ok,
-                                          adapt.offered ? adapt.low16_shift : 0u, hybrid_local_sort_grid(plan->ctx->num_cus), s))
+                                          adapt.offered ? adapt.low16_shift : 0u, hybrid_local_sort_grid(plan->ctx->num_cus, split.big), s,
+                                          split.big))
         return rc;
     if (int rc = mark(plan, "msd_local_sort", s)) return rc;
     // ... of the oversized ones (the device's list; usually empty, and then these launches are a few
@@ -1370,8 +1382,8 @@ extern "C" int mrs_hybrid_split_for(uint64_t n, int32_t begin_bit, int32_t end_b
     if (!out) return fail(MRS_ERR_INVALID_ARGUMENT, "mrs_hybrid_split_for: null output");
     std::memset(out, 0, sizeof *out);
     const int width = end_bit - begin_bit;
-    if (begin_bit < 0 || end_bit > 32 || width < 25 || n == 0 || n >= (1ull << 30))
-        return fail(MRS_ERR_UNSUPPORTED, "mrs_hybrid_split_for: MRS_ALGO_HYBRID sorts 25 to 32 bits of a 32-bit key, 0 < n < 2^30");
+    if (begin_bit < 0 || end_bit > 32 || width < 25 || n == 0 || n > (1ull << 30))
+        return fail(MRS_ERR_UNSUPPORTED, "mrs_hybrid_split_for: MRS_ALGO_HYBRID sorts 25 to 32 bits of a 32-bit key, 0 < n <= 2^30");
     HybridSplit split{};
     out->offered = hybrid_choose_split(begin_bit, end_bit, n, window, TestAids{}, &split) ? 1 : 0;
     if (!out->offered && window) return MRS_OK;  // no split exists for this window

@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(1024) void hybrid_big_histogram_kernel(const uint32
 // COUNTS: the segment table's digit_base holds the digit COUNTS of each segment, not yet the places
 // of the digits' runs (the passes over oversized sub-buckets: their histogram kernel leaves counts);
 // every tile turns its segment's 256 counts into places, in `s_bases`.
-template <bool SEG, bool PERSISTENT, int MAP, int THREADS, int KPT, bool COUNTS = false>
+template <bool SEG, bool PERSISTENT, int MAP, int THREADS, int KPT, bool COUNTS = false, typename StatusT = uint32_t>
 __device__ __forceinline__ void gated_pass(const PassArgs& a, const SegmentTable& seg,
                                            PassShared<8, THREADS, KPT, uint32_t, uint32_t>& sh, uint32_t (&s_seg)[4],
                                            const HybridTables* __restrict__ tables = nullptr, uint32_t* s_entry = nullptr,
@@ -1146,16 +1146,16 @@ __device__ __forceinline__ void gated_pass(const PassArgs& a, const SegmentTable
                 b.digit_base = s_bases;
             }
             if (remaining >= static_cast<uint32_t>(S::TILE))
-                process_tile<kModeOnesweep, kRankAtomic, MAP, true, uint32_t>(b, sh, tile, S::TILE, base, first, tid);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, true, StatusT>(b, sh, tile, S::TILE, base, first, tid);
             else
-                process_tile<kModeOnesweep, kRankAtomic, MAP, false, uint32_t>(b, sh, tile, remaining, base, first, tid);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, false, StatusT>(b, sh, tile, remaining, base, first, tid);
         } else {
             const uint32_t remaining = a.n - tile * static_cast<uint32_t>(S::TILE);
             const unsigned long long base = static_cast<unsigned long long>(tile) * S::TILE;
             if (remaining >= static_cast<uint32_t>(S::TILE))
-                process_tile<kModeOnesweep, kRankAtomic, MAP, true, uint32_t>(a, sh, tile, S::TILE, base, 0u, tid);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, true, StatusT>(a, sh, tile, S::TILE, base, 0u, tid);
             else
-                process_tile<kModeOnesweep, kRankAtomic, MAP, false, uint32_t>(a, sh, tile, remaining, base, 0u, tid);
+                process_tile<kModeOnesweep, kRankAtomic, MAP, false, StatusT>(a, sh, tile, remaining, base, 0u, tid);
         }
         if (!PERSISTENT) return;
         // A look-back that gave up has raised the plan's error flag: the output is lost, the ticket of
@@ -1172,7 +1172,9 @@ __device__ __forceinline__ void gated_pass(const PassArgs& a, const SegmentTable
 // ADAPT: the launch also holds the same pass of the adaptive schedule (`adapt`; pass A by the byte
 // table adapt.digit_map, pass B over the same segment table by the groups of `tables`).
 enum PassRole { kPassA = 0, kPassB = 1, kPassOversized = 2, kPassOrdinary = 3 };
-template <bool SEG, bool DUAL, bool PERSISTENT, int MAP, int THREADS, int KPT, int ROLE, bool ADAPT>
+// OTHER_WIDE: `other` uses 64-bit tile status words and 64-bit addressing (plans of 2^30 pairs, whose
+// ordinary passes can count 2^30 keys in one digit; `run` and `adapt` never do).
+template <bool SEG, bool DUAL, bool PERSISTENT, int MAP, int THREADS, int KPT, int ROLE, bool ADAPT, bool OTHER_WIDE = false>
 __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs run, const SegmentTable seg,
                                                                   const PassArgs other, const HybridHeader* __restrict__ hdr,
                                                                   const PassArgs adapt, const HybridTables* __restrict__ tables)
@@ -1212,7 +1214,10 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
         }
     }
     if constexpr (DUAL) {
-        if (mode == kHybFallback) gated_pass<false, PERSISTENT, kMapNone, THREADS, KPT>(other, seg, sh, s_seg);
+        if (mode == kHybFallback) {
+            if constexpr (OTHER_WIDE) gated_pass<false, PERSISTENT, kMapNone, THREADS, KPT, false, unsigned long long>(other, seg, sh, s_seg);
+            else gated_pass<false, PERSISTENT, kMapNone, THREADS, KPT>(other, seg, sh, s_seg);
+        }
     }
 }
 
@@ -1231,8 +1236,9 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
 // write-out.
 constexpr uint32_t kLocalMinGrid = 256;  // so that a workgroup has at most this many sub-buckets
 constexpr uint32_t kLocalMaxPerGroup = kHybSubs / kLocalMinGrid;
-constexpr int kLocalStageBytes = kHybLocalThreads * kHybLocalKptFull * 8;
-static_assert(kLocalStageBytes >= kHybLocalThreads * kHybLocalKptCompact * 6, "both stagings fit the same LDS");
+constexpr int local_stage_bytes(int threads, int kpt, bool compact) { return threads * kpt * (compact ? 6 : 8); }
+static_assert(local_stage_bytes(kHybLocalThreads, kHybLocalKptFull, false) == local_stage_bytes(kHybLocalThreads, kHybLocalKptCompact, true),
+              "both stagings of the 512-thread workgroup take the same LDS");
 
 template <int THREADS, int KPT, bool COMPACT>
 __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t* __restrict__ keys,
@@ -1247,9 +1253,9 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
     constexpr int RADIX = 256;
     constexpr uint32_t CAP = THREADS * KPT;
     static_assert(THREADS >= RADIX, "one thread per digit in the scan");
-    // 60 KiB: two workgroups fit a compute unit's 160 KiB.  Full: (key, payload) per slot.
-    // Compact: CAP payloads, then CAP 16-bit keys.
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLocalStageBytes];
+    // 60 KiB with 512 threads: two workgroups fit a compute unit's 160 KiB (120 KiB with 1024: one).
+    // Full: (key, payload) per slot.  Compact: CAP payloads, then CAP 16-bit keys.
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[local_stage_bytes(THREADS, KPT, COMPACT)];
     __shared__ uint32_t s_hist[2][WAVES][RADIX];
     __shared__ uint32_t s_wsum[2][4];
     __shared__ uint32_t s_span[kLocalMaxPerGroup];  // adaptive groups: the low key bits in which a group's keys can differ
@@ -1458,10 +1464,10 @@ int hybrid_histogram_grid(int num_cus, uint64_t n)
     return g == 0 ? 1 : static_cast<int>(g);
 }
 
-int hybrid_local_sort_grid(int num_cus)
+int hybrid_local_sort_grid(int num_cus, bool big)
 {
-    // 78 KiB of LDS each: two per compute unit
-    const int g = num_cus * 2;
+    // 78 KiB of LDS each: two per compute unit (154 KiB: one)
+    const int g = big ? num_cus : num_cus * 2;
     return g < static_cast<int>(kLocalMinGrid) ? static_cast<int>(kLocalMinGrid) : g;
 }
 
@@ -1483,8 +1489,8 @@ int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, H
                        const AdaptArgs& adapt, uint32_t* ghist, uint32_t begin_bit, uint32_t end_bit, uint32_t shift,
                        uint32_t window_base, hipStream_t s)
 {
-    if (cap == 0 || cap > (compact_ok ? kHybLocalCapCompact : kHybLocalCapFull))
-        return fail(MRS_ERR_INVALID_ARGUMENT, "a workgroup of the local sort holds at most %u pairs", compact_ok ? kHybLocalCapCompact : kHybLocalCapFull);
+    if (cap == 0 || cap > (compact_ok ? kHybLocalCapBig : kHybLocalCapFull))
+        return fail(MRS_ERR_INVALID_ARGUMENT, "a workgroup of the local sort holds at most %u pairs", compact_ok ? kHybLocalCapBig : kHybLocalCapFull);
     if (adapt.offered && (adapt.msd_bits < kAdaptCellBits || adapt.msd_bits > 16u || adapt.cell_shift < adapt.low16_shift ||
                           adapt.cell_shift - adapt.low16_shift > 4u || adapt.low16_shift < 16u))
         return fail(MRS_ERR_UNSUPPORTED, "the adaptive schedule needs 28 to 32 sorted key bits");
@@ -1521,6 +1527,17 @@ static int launch_pass_shape(int threads, int kpt, const PassArgs& run, const Se
                              const HybridHeader* hdr, uint32_t grid, hipStream_t s, const PassArgs& adapt = PassArgs{},
                              const HybridTables* tables = nullptr)
 {
+    if (other.wide_status) {
+        if constexpr (DUAL && PERSISTENT) {
+            if (threads != 1024 || kpt != 32) return fail(MRS_ERR_UNSUPPORTED, "plans of 2^30 pairs use tiles of 1024 x 32 keys");
+            hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 1024, 32, ROLE, ADAPT, true>), dim3(grid), dim3(1024), 0, s, run,
+                               seg, other, hdr, adapt, tables);
+            MRS_CHECK_LAUNCH("hybrid_pass_kernel");
+            return MRS_OK;
+        } else {
+            return fail(MRS_ERR_UNSUPPORTED, "only persistent launches carry an ordinary pass with 64-bit status words");
+        }
+    }
     if (threads == 1024 && kpt == 32)
         hipLaunchKernelGGL((hybrid_pass_kernel<SEG, DUAL, PERSISTENT, MAP, 1024, 32, ROLE, ADAPT>), dim3(grid), dim3(1024), 0, s, run, seg,
                            other, hdr, adapt, tables);
@@ -1538,8 +1555,8 @@ int hybrid_launch_pass(int role, const PassArgs* run, const SegmentTable* seg, c
                        const HybridTables* tables)
 {
     if (!run && !other) return fail(MRS_ERR_INVALID_ARGUMENT, "a gated pass needs at least one description");
-    if ((run && run->wide_status) || (other && other->wide_status) || (adapt && adapt->wide_status))
-        return fail(MRS_ERR_UNSUPPORTED, "gated passes use 32-bit tile status words");
+    if ((run && run->wide_status) || (adapt && adapt->wide_status))
+        return fail(MRS_ERR_UNSUPPORTED, "the passes of the three-move schedule use 32-bit tile status words");
     if (adapt && (!tables || !persistent || windowed || role > kPassB))
         return fail(MRS_ERR_UNSUPPORTED, "the adaptive schedule's passes are persistent launches of pass A and pass B");
     const PassArgs& ad = adapt ? *adapt : PassArgs{};
@@ -1598,8 +1615,10 @@ int hybrid_launch_big_histogram(const uint32_t* keys, HybridTables* tables, Hybr
 
 int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,
                              uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, uint32_t key_shift,
-                             bool compact_ok, uint32_t adapt_low16, int grid, hipStream_t s)
+                             bool compact_ok, uint32_t adapt_low16, int grid, hipStream_t s, bool big)
 {
+    if (big && (!compact_ok || adapt_low16 != 0u))
+        return fail(MRS_ERR_UNSUPPORTED, "the 1024-thread local sort stages 6 bytes per pair and serves the fixed split only");
     if (adapt_low16 != 0u && (adapt_low16 < 16u || (compact_ok && adapt_low16 != 16u)))
         return fail(MRS_ERR_UNSUPPORTED, "the adaptive schedule's groups are sorted on 16 bits, staged in 6 bytes only if those are the low 16");
     if (num_subs == 0 || num_subs > kHybSubs) return fail(MRS_ERR_UNSUPPORTED, "at most 65536 sub-buckets");
@@ -1607,7 +1626,10 @@ int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader*
         return fail(MRS_ERR_UNSUPPORTED, "the local sort takes two digits of 1 to 8 bits");
     if (compact_ok && key_shift > 16) return fail(MRS_ERR_INVALID_ARGUMENT, "6-byte staging needs the sub-bucket's bits to start at bit 16 or below");
     const ProfilerRange range("Local sort");
-    if (compact_ok)
+    if (big)
+        hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreadsBig, kHybLocalKptCompact, true>), dim3(grid), dim3(kHybLocalThreadsBig),
+                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift, adapt_low16);
+    else if (compact_ok)
         hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreads, kHybLocalKptCompact, true>), dim3(grid), dim3(kHybLocalThreads),
                            0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift, adapt_low16);
     else

@@ -73,6 +73,10 @@ constexpr int kHybLocalKptFull = 15;    // pairs per thread at most when a pair 
 constexpr int kHybLocalKptCompact = MRS_LOCAL_KPT_COMPACT; // ... when it takes 6
 constexpr uint32_t kHybLocalCapFull = kHybLocalThreads * kHybLocalKptFull;        // 7680
 constexpr uint32_t kHybLocalCapCompact = kHybLocalThreads * kHybLocalKptCompact;  // 10240
+// Inputs whose evenly spread sub-buckets no longer fit that (2^29.1 to 2^30 pairs): one workgroup of
+// 1024 threads per compute unit, 6-byte staging only.
+constexpr int kHybLocalThreadsBig = 1024;
+constexpr uint32_t kHybLocalCapBig = kHybLocalThreadsBig * kHybLocalKptCompact;   // 20480
 constexpr uint32_t kHybPackedWords = kHybSubs / 2;  // one workgroup's 16-bit counters, two to a word
 constexpr uint32_t kHybMaxBig = 256;    // oversized sub-buckets one call sorts where they lie
 
@@ -163,7 +167,7 @@ struct SegmentTable {
 size_t hybrid_tables_bytes();
 size_t hybrid_packed_bytes(int grid);
 int hybrid_histogram_grid(int num_cus, uint64_t n);
-int hybrid_local_sort_grid(int num_cus);
+int hybrid_local_sort_grid(int num_cus, bool big = false);
 
 // Exact histogram of the `bits` <= 16 key bits from `shift` up: one packed table per workgroup
 // plus the spill counts in `hc`.  windowed: of (key >> shift) - window_base instead, which must be
@@ -200,6 +204,8 @@ int hybrid_launch_adapt_count(const uint32_t* keys, HybridTables* tables, Hybrid
 // windowed: the digits are fields of (key >> shift) - window_base (PassArgs).
 // role: which launch of the schedule this is (0 pass A, 1 pass B, 2 a pass over the oversized
 // sub-buckets, 3 an ordinary pass on its own); it selects the kernel's name, nothing else.
+// An `other` with 64-bit tile status words (plans of 2^30 pairs) is served by launches of their own
+// kind; `run` and `adapt` always use 32-bit words (no digit of theirs counts 2^30 keys).
 // `adapt`: null, or (roles 0 and 1, persistent) the same pass of the adaptive schedule, taken if the
 // device chose that one: pass A by the table adapt->digit_map over the bits from adapt->shift up,
 // pass B over the same segment table by the group numbers of `tables` (adapt->shift: first bit of a
@@ -216,9 +222,10 @@ int hybrid_launch_big_histogram(const uint32_t* keys, HybridTables* tables, Hybr
 // hybrid_launch_scan (6-byte staging; the decision kernel has refused the schedule if the bits
 // above the sorted range vary).  adapt_low16: 0, or the adaptive schedule is offered and its groups
 // (65536 table entries) are sorted on the two 8-bit digits below bit adapt_low16.
+// big: the workgroups of 1024 threads that hold kHybLocalCapBig pairs (6-byte staging only).
 int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,
                              uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, uint32_t key_shift,
-                             bool compact_ok, uint32_t adapt_low16, int grid, hipStream_t s);
+                             bool compact_ok, uint32_t adapt_low16, int grid, hipStream_t s, bool big = false);
 
 }  // namespace mrs
 

@@ -147,6 +147,7 @@ struct TestAids {
     bool hybrid_force_adaptive = false;  // the fixed sub-buckets are passed over: buckets and groups cut to the keys
     bool hybrid_no_adaptive = false;     // that schedule is not offered
     uint32_t hybrid_capacity = 0;        // 0 = what a workgroup of the local sort holds; less: more groups, more oversized ones
+    bool hybrid_big_local = false;       // the local sort's workgroups of 1024 threads at any size (where 6-byte staging applies)
     bool no_small_sort = false;
     bool no_pass_skip = false;
     bool wide_status = false;
