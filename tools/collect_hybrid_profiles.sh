@@ -22,6 +22,7 @@ pmc() {  # pmc NAME COUNTER command...
 }
 stats hybrid_bench python3 bench.py --steps 10 --warmup 3 --no-extras &&
 stats hybrid_2p29 python3 tools/sort_once.py --log2n 29 --iters 4 --algo hybrid --end-bit 30 &&
+stats hybrid_2p30 python3 tools/sort_once.py --log2n 30 --iters 4 --algo hybrid --end-bit 30 &&
 stats hybrid_cluster python3 tools/sort_once.py --log2n 28 --iters 4 --algo hybrid --end-bit 30 --dist cluster5 &&
 stats hybrid_2p26 python3 tools/sort_once.py --log2n 26 --iters 4 --algo hybrid --end-bit 30 &&
 stats hybrid_surface python3 tools/sort_once.py --log2n 28 --iters 4 --algo hybrid --end-bit 30 --dist surface &&

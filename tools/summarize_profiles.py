@@ -60,8 +60,8 @@ def summarize_hybrid(args, n, library_rows):
                 "bytes_per_launch": f * 1024.0 * factor + w * 1024.0 * cal_w, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w}
 
     # the last but one template argument of hybrid_pass_kernel names the launch: 0 pass A, 1 pass B
-    a = traffic("32, 0, true>(")
-    b = traffic("32, 1, true>(")
+    a = traffic("1024, 32, 0, ")
+    b = traffic("1024, 32, 1, ")
     entry = {
         "kernel": "hybrid_pass_kernel (mean of pass A and pass B)",
         "n": n,
