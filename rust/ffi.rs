@@ -14,6 +14,7 @@ pub const ALGO_HYBRID: i32 = 2;
 pub const SCHEDULE_PASSES: i32 = 0;
 pub const SCHEDULE_MSD: i32 = 1;
 pub const SCHEDULE_MSD_REFUSED: i32 = 2;
+pub const SCHEDULE_MSD_ADAPTIVE: i32 = 3;
 pub const MORTON_UNIFORMS_BYTES: usize = 51248;
 
 #[repr(C)]
