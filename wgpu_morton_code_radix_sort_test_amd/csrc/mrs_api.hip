@@ -1217,8 +1217,10 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     // schedule (a fixed sub-bucket's own bits end at or below them, and what lies above is constant
     // inside it).
     const uint32_t big1 = adapt.offered ? 8u : bits1, big2 = adapt.offered ? 8u : bits2;
+    // (the launch is also ordinary pass 1 of the other schedule)
     if (int rc = hybrid_launch_big_histogram(static_cast<const uint32_t*>(keys_a), plan->hyb_tables, hc, plan->tile_items,
-                                             begin_bit, big1, big2, static_cast<int>(cus), s))
+                                             begin_bit, big1, big2, &ordinary[1], plan->threads, plan->kpt,
+                                             static_cast<int>(persistent_grid), s))
         return rc;
     if (int rc = mark(plan, "msd_oversized_histogram", s)) return rc;
     const size_t big_region = hybrid_tiles_big(num_tiles) * per_tile;
@@ -1238,14 +1240,11 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
         a.xcd_block = xcd_block;
         const SegmentTable oversized{plan->hyb_tables->big_first_tile, plan->hyb_tables->big_start, plan->hyb_tables->big_end,
                                      &hc->big_hist[0][hh][0], 512u, &hc->hdr.num_tiles_big};
-        if (int rc = hybrid_launch_pass(2, &a, &oversized, &ordinary[1 + hh], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
+        if (int rc = hybrid_launch_pass(2, &a, &oversized, &ordinary[2 + hh], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
             return rc;
         if (int rc = mark(plan, "msd_oversized_pass", s)) return rc;
     }
-    // the last ordinary pass has a launch of its own
-    if (int rc = hybrid_launch_pass(3, nullptr, nullptr, &ordinary[3], true, false, plan->threads, plan->kpt, hdr, persistent_grid, s))
-        return rc;
-    return mark(plan, "fallback_pass", s);
+    return MRS_OK;
 }
 
 // The launch schedule shared by mrs_sort_pairs, mrs_sort_pairs_primed, mrs_sort_pairs_indexed and

@@ -954,15 +954,30 @@ __global__ __launch_bounds__(1024) void hybrid_adapt_count_kernel(const uint32_t
 // ---- the oversized sub-buckets: digit counts and run positions -------------------------------
 // counts of the two local digits of every oversized sub-bucket, tile by tile of the passes that
 // will move them (a tile never straddles two of them)
-__global__ __launch_bounds__(1024) void hybrid_big_histogram_kernel(const uint32_t* __restrict__ keys, HybridTables* tb,
-                                                                     HybridCleared* hc, uint32_t tile_items, uint32_t shift,
-                                                                     uint32_t bits1, uint32_t bits2)
+struct BigHistogramArgs {
+    const uint32_t* keys;
+    HybridTables* tb;
+    HybridCleared* hc;
+    uint32_t tile_items, shift, bits1, bits2;
+};
+struct BigHistogramShared {
+    uint32_t h[2][256];
+    uint32_t seg[3];
+    uint32_t ft[4];
+};
+// (a device function: the launch it runs in is also an ordinary pass of the other schedule, see
+// hybrid_big_histogram_kernel)
+template <int THREADS>
+__device__ __forceinline__ void big_histogram(const BigHistogramArgs& g, BigHistogramShared& sm, const uint32_t mode)
 {
-    __shared__ uint32_t s_h[2][256];
-    __shared__ uint32_t s_seg[3];
-    __shared__ uint32_t s_ft[4];
-    const uint32_t mode = hybrid_mode(hc->hdr);  // uniform
-    if (mode != kHybRun && mode != kHybAdapt) return;
+    static_assert(THREADS >= 512, "a thread per counter of the two digits");
+    const uint32_t* __restrict__ keys = g.keys;
+    HybridTables* tb = g.tb;
+    HybridCleared* hc = g.hc;
+    const uint32_t tile_items = g.tile_items, shift = g.shift, bits1 = g.bits1, bits2 = g.bits2;
+    uint32_t (&s_h)[2][256] = sm.h;
+    uint32_t (&s_seg)[3] = sm.seg;
+    uint32_t (&s_ft)[4] = sm.ft;
     const uint32_t tid = threadIdx.x;
     uint32_t num_tiles = hc->hdr.num_tiles_big;
     uint32_t ft0 = 0, ft1 = 0, bs0 = 0, bs1 = 0;
@@ -1013,7 +1028,7 @@ __global__ __launch_bounds__(1024) void hybrid_big_histogram_kernel(const uint32
         const uint32_t seg = s_seg[0], base = s_seg[1];
         const uint32_t left = s_seg[2] - base;
         const uint32_t cnt = left < tile_items ? left : tile_items;
-        for (uint32_t i = tid; i < cnt; i += 1024) {
+        for (uint32_t i = tid; i < cnt; i += THREADS) {
             const uint32_t k = keys[base + i];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1218,6 +1233,27 @@ __global__ __launch_bounds__(THREADS, 1) void hybrid_pass_kernel(const PassArgs 
             if constexpr (OTHER_WIDE) gated_pass<false, PERSISTENT, kMapNone, THREADS, KPT, false, unsigned long long>(other, seg, sh, s_seg);
             else gated_pass<false, PERSISTENT, kMapNone, THREADS, KPT>(other, seg, sh, s_seg);
         }
+    }
+}
+
+// The digit counts of the oversized sub-buckets (three-move schedules) or, if the device chose the
+// ordinary passes, one of those: the two never run in the same call, and a launch of its own for
+// either would have nothing to do in most calls.
+template <int THREADS, int KPT, bool OTHER_WIDE>
+__global__ __launch_bounds__(THREADS, 1) void hybrid_big_histogram_kernel(const BigHistogramArgs g, const PassArgs other,
+                                                                           const HybridHeader* __restrict__ hdr)
+{
+    using S = PassShared<8, THREADS, KPT, uint32_t, uint32_t>;
+    __shared__ S sh;
+    __shared__ uint32_t s_seg[4];
+    __shared__ BigHistogramShared sm;
+    const uint32_t mode = hybrid_mode(*hdr);  // uniform
+    if (mode == kHybRun || mode == kHybAdapt) {
+        big_histogram<THREADS>(g, sm, mode);
+    } else if (mode == kHybFallback && other.keys_in != nullptr) {
+        const SegmentTable none{};
+        if constexpr (OTHER_WIDE) gated_pass<false, true, kMapNone, THREADS, KPT, false, unsigned long long>(other, none, sh, s_seg);
+        else gated_pass<false, true, kMapNone, THREADS, KPT>(other, none, sh, s_seg);
     }
 }
 
@@ -1600,16 +1636,26 @@ int hybrid_launch_pass(int role, const PassArgs* run, const SegmentTable* seg, c
 }
 
 int hybrid_launch_big_histogram(const uint32_t* keys, HybridTables* tables, HybridCleared* hc, uint32_t tile_items,
-                                uint32_t shift, uint32_t bits1, uint32_t bits2, int grid, hipStream_t s)
+                                uint32_t shift, uint32_t bits1, uint32_t bits2, const PassArgs* other, int threads, int kpt,
+                                int grid, hipStream_t s)
 {
     if (bits1 == 0 || bits1 > 8 || bits2 == 0 || bits2 > 8)
         return fail(MRS_ERR_UNSUPPORTED, "oversized sub-buckets are sorted on two digits of 1 to 8 bits");
-    {
-        const ProfilerRange range("Histogram calculation");  // src/main.rs:597
-        hipLaunchKernelGGL(hybrid_big_histogram_kernel, dim3(grid < 1 ? 1 : grid), dim3(1024), 0, s, keys, tables, hc, tile_items,
-                           shift, bits1, bits2);
-        MRS_CHECK_LAUNCH("hybrid_big_histogram_kernel");
+    const ProfilerRange range("Histogram calculation");  // src/main.rs:597
+    const BigHistogramArgs g{keys, tables, hc, tile_items, shift, bits1, bits2};
+    const PassArgs o = other ? *other : PassArgs{};
+    const dim3 blocks(grid < 1 ? 1 : grid);
+    if (threads == 1024 && kpt == 32) {
+        if (o.wide_status)
+            hipLaunchKernelGGL((hybrid_big_histogram_kernel<1024, 32, true>), blocks, dim3(1024), 0, s, g, o, &hc->hdr);
+        else
+            hipLaunchKernelGGL((hybrid_big_histogram_kernel<1024, 32, false>), blocks, dim3(1024), 0, s, g, o, &hc->hdr);
+    } else if (threads == 512 && kpt == 8 && !o.wide_status) {
+        hipLaunchKernelGGL((hybrid_big_histogram_kernel<512, 8, false>), blocks, dim3(512), 0, s, g, o, &hc->hdr);
+    } else {
+        return fail(MRS_ERR_UNSUPPORTED, "no kernel for %d threads x %d keys per thread", threads, kpt);
     }
+    MRS_CHECK_LAUNCH("hybrid_big_histogram_kernel");
     return MRS_OK;
 }
 

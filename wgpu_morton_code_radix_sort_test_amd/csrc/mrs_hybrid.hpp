@@ -214,9 +214,12 @@ int hybrid_launch_pass(int role, const PassArgs* run, const SegmentTable* seg, c
                        int threads, int kpt, const HybridHeader* hdr, uint32_t grid, hipStream_t s,
                        const PassArgs* adapt = nullptr, const HybridTables* tables = nullptr);
 // Digit counts of the oversized sub-buckets on bits [shift, shift + bits1) and the bits2 above
-// them (the passes over them turn the counts into run positions tile by tile).
+// them (the passes over them turn the counts into run positions tile by tile).  `other`: null, or the
+// ordinary pass the same launch runs if the device chose those (persistent, `grid` workgroups of
+// `threads`, the plan's tile shape).
 int hybrid_launch_big_histogram(const uint32_t* keys, HybridTables* tables, HybridCleared* hc, uint32_t tile_items,
-                                uint32_t shift, uint32_t bits1, uint32_t bits2, int grid, hipStream_t s);
+                                uint32_t shift, uint32_t bits1, uint32_t bits2, const PassArgs* other, int threads, int kpt,
+                                int grid, hipStream_t s);
 // Sorts every sub-bucket that fits a workgroup in place on bits [shift, shift + bits1 + bits2).
 // key_shift: key bits from here up are the same for all keys of a sub-bucket; compact_ok as for
 // hybrid_launch_scan (6-byte staging; the decision kernel has refused the schedule if the bits
