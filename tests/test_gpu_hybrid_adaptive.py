@@ -214,3 +214,43 @@ def test_fuzz(ctx, oracle, mrs, small):
         assert np.array_equal(ko, rk), what
         assert np.array_equal(vo, rv), what
     assert mrs.SortPlan.SCHEDULE_MSD_ADAPTIVE in seen
+
+
+def test_replays_from_a_graph(ctx, oracle, mrs, small, aids):
+    """All three schedules are enqueued by every call and nothing on the host waits for the device's
+    choice, so one captured call serves spread keys (fixed sub-buckets), surface keys (buckets and
+    groups cut to them) and equal keys (ordinary passes) alike."""
+    aids(ctx.ATTR_TEST_HYBRID_CAPACITY, 60)
+    n = 300000
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, end_bit=30, algo=mrs.ALGO_HYBRID)
+    ka = torch.zeros(n, dtype=torch.int32, device=ctx.device)
+    va, kb, vb = torch.zeros_like(ka), torch.zeros_like(ka), torch.zeros_like(ka)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ka.copy_(to_dev(make_keys(oracle, n, 1, "morton30", seed=1), ctx.device))
+        plan.sort_pairs(ka, va, kb, vb, stream=side)  # warm-up outside the capture
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        in_b = plan.sort_pairs(ka, va, kb, vb, stream=torch.cuda.current_stream())
+    assert not in_b
+    seen = []
+    for shape in ("morton30", "surface", "all_equal", "surface", "morton30"):
+        if shape == "surface":
+            keys = _surface_codes(n, seed=len(seen))
+        else:
+            keys = make_keys(oracle, n, 1, shape, seed=3) & np.uint32(0x3FFFFFFF)
+        vals = make_vals(oracle, n, 1)
+        ka.copy_(to_dev(keys, ctx.device))
+        va.copy_(to_dev(vals, ctx.device))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        seen.append(plan.schedule()[0])
+        rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 30)
+        assert np.array_equal(to_u32(ka), rk) and np.array_equal(to_u32(va), rv), (shape, seen)
+    assert seen[1] == mrs.SortPlan.SCHEDULE_MSD_ADAPTIVE and seen[2] == mrs.SortPlan.SCHEDULE_MSD_REFUSED, seen
+    plan.check()
+    del graph
+    plan.close()
