@@ -1379,8 +1379,25 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
 #pragma unroll
             for (int i = 0; i < KU; ++i) {
                 uint32_t r = 0;
+#ifdef MRS_LOCAL_RANK_MATCH  // A/B builds: ballots instead of returning atomics
+                {
+                    const bool mine = static_cast<uint32_t>(i) < ku && element(ku, i) < cnt;
+                    const uint32_t d = __builtin_amdgcn_ubfe(key[i], sh, wd);
+                    const unsigned long long valid = __ballot(mine);
+                    if (valid != 0ull) {  // uniform
+                        uint32_t mlo, mhi;
+                        match_digit<8>(d, valid, &mlo, &mhi);
+                        const uint32_t below = lanes_below(mlo, mhi);
+                        const uint32_t prev = s_hist[h][wave][d];
+                        if (mine && below == 0u) s_hist[h][wave][d] = prev + __popc(mlo) + __popc(mhi);
+                        r = prev + below;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+#else
                 if (static_cast<uint32_t>(i) < ku && element(ku, i) < cnt)
                     r = atomicAdd(&s_hist[h][wave][__builtin_amdgcn_ubfe(key[i], sh, wd)], 1u);
+#endif
                 pos.set_fresh(i, r);
             }
             __syncthreads();  // every key is counted (and, h == 1, every slot of the stage has been read)
