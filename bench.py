@@ -531,7 +531,7 @@ def main():
             for label, log2m, eb, shape in () if args.no_extras else (("2^26", 26, 30, "uniform"), ("2^27", 27, 30, "uniform"), ("2^29", 29, 30, "uniform"),
                                             ("2^28 uniform + 5 % cluster", 28, 30, "cluster"),
                                             ("2^28 surface (sphere shell + three planes)", 28, 30, "surface"),
-                                            ("2^28 all equal", 28, 30, "equal"), ("2^28 refused", 28, 32, "uniform")):
+                                            ("2^28 all equal", 28, 30, "equal"), ("2^28 30-bit codes declared as 32-bit keys", 28, 32, "uniform")):
                 m = 1 << log2m
                 if m > n and log2m != 29:  # the ping-pong buffers are the headline's
                     continue
