@@ -25,16 +25,21 @@ def small(ctx, aids):
     aids(ctx.ATTR_TEST_HYBRID_MIN_N, 1)
 
 
-def _sort(ctx, mrs, keys, vals, n, end, twice=False):
+def _sort(ctx, mrs, keys, vals, n, end, twice=False, indexed=False):
+    """`indexed`: the payload is made up by the first pass (mrs_sort_pairs_indexed; `vals` must be 0 .. n-1)."""
     plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, begin_bit=0, end_bit=end, algo=mrs.ALGO_HYBRID)
     ka, va = to_dev(keys, ctx.device), to_dev(vals, ctx.device)
+    if indexed:
+        va.fill_(0x5A5A5A5A)
     kb, vb = torch.full_like(ka, -1), torch.full_like(va, -1)
-    in_b = plan.sort_pairs(ka, va, kb, vb, n=n)
+    sort = plan.sort_pairs_indexed if indexed else plan.sort_pairs
+    in_b = sort(ka, va, kb, vb, n=n)
     plan.check()
     if twice:
         ka.copy_(to_dev(keys, ctx.device))
-        va.copy_(to_dev(vals, ctx.device))
-        in_b = plan.sort_pairs(ka, va, kb, vb, n=n)
+        if not indexed:
+            va.copy_(to_dev(vals, ctx.device))
+        in_b = sort(ka, va, kb, vb, n=n)
         plan.check()
     schedule, largest = plan.schedule()
     over = plan.oversized()
@@ -201,14 +206,15 @@ def test_fuzz(ctx, oracle, mrs, small):
         forced = bool(rng.randint(2))
         ctx.set_attribute(ctx.ATTR_TEST_HYBRID_CAPACITY, capacity)
         ctx.set_attribute(ctx.ATTR_TEST_HYBRID_FORCE_ADAPTIVE, 1 if forced else 0)
+        indexed = bool(rng.randint(3) == 0)
         try:
-            vals = make_vals(oracle, n, 1)
-            ko, vo, in_b, schedule, largest, over = _sort(ctx, mrs, keys, vals, n, end, twice=bool(rng.randint(2)))
+            vals = np.arange(n, dtype=np.uint32) if indexed else make_vals(oracle, n, 1)
+            ko, vo, in_b, schedule, largest, over = _sort(ctx, mrs, keys, vals, n, end, twice=bool(rng.randint(2)), indexed=indexed)
         finally:
             ctx.set_attribute(ctx.ATTR_TEST_HYBRID_CAPACITY, 0)
             ctx.set_attribute(ctx.ATTR_TEST_HYBRID_FORCE_ADAPTIVE, 0)
         rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, end)
-        what = (case, n, end, shape, capacity, forced, schedule, largest, over)
+        what = (case, n, end, shape, capacity, forced, indexed, schedule, largest, over)
         seen.add(schedule)
         assert not in_b, what
         assert np.array_equal(ko, rk), what
