@@ -260,3 +260,26 @@ def test_replays_from_a_graph(ctx, oracle, mrs, small, aids):
     plan.check()
     del graph
     plan.close()
+
+
+@pytest.mark.parametrize("offset", [1, 2, 3])
+def test_misaligned_buffers(ctx, oracle, mrs, small, aids, offset):
+    """Key and payload arrays that start 4, 8 or 12 bytes past a 16-byte boundary (the kernel that
+    counts a bucket reads 16 bytes at a time where it can); nothing is written outside them."""
+    aids(ctx.ATTR_TEST_HYBRID_CAPACITY, 100)
+    n = 333337
+    keys = _surface_codes(n, seed=offset)
+    vals = make_vals(oracle, n, 1)
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, end_bit=30, algo=mrs.ALGO_HYBRID)
+    bufs = [torch.zeros(n + 8, dtype=torch.int32, device=ctx.device) for _ in range(4)]
+    ka, va, kb, vb = (b[offset:n + offset] for b in bufs)
+    ka.copy_(to_dev(keys, ctx.device))
+    va.copy_(to_dev(vals, ctx.device))
+    in_b = plan.sort_pairs(ka, va, kb, vb)
+    plan.check()
+    assert plan.schedule()[0] == plan.SCHEDULE_MSD_ADAPTIVE and not in_b
+    rk, rv = oracle.stable_sort_pairs(keys, vals, n, 1, 1, 0, 30)
+    assert np.array_equal(to_u32(ka), rk) and np.array_equal(to_u32(va), rv)
+    for b in bufs:
+        assert int(b[:offset].abs().sum()) == 0 and int(b[n + offset:].abs().sum()) == 0
+    plan.close()
