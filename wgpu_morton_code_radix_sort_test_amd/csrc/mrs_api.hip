@@ -1206,7 +1206,7 @@ static int sort_pairs_hybrid(mrs_plan* plan, uint32_t n32, void* keys_a, void* v
     if (int rc = hybrid_launch_local_sort(static_cast<uint32_t*>(keys_a), static_cast<uint32_t*>(vals_a), hdr, plan->hyb_tables,
                                           begin_bit, bits1, bits2, 1u << msd_bits, split.shift, compact_ok,
                                           adapt.offered ? adapt.low16_shift : 0u, hybrid_local_sort_grid(plan->ctx->num_cus, split.big), s,
-                                          split.big))
+                                          split.big, /* stream_out: 8 n bytes against a last-level cache of 256 MiB */ n32 > (3u << 26)))
         return rc;
     if (int rc = mark(plan, "msd_local_sort", s)) return rc;
     // ... of the oversized ones (the device's list; usually empty, and then these launches are a few

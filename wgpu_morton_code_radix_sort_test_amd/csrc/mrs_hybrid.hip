@@ -1283,7 +1283,8 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
                                                                      const HybridTables* __restrict__ tb,
                                                                      const uint32_t run_shift, const uint32_t run_bits1,
                                                                      const uint32_t run_bits2, const uint32_t run_subs,
-                                                                     const uint32_t run_key_shift, const uint32_t adapt_low16)
+                                                                     const uint32_t run_key_shift, const uint32_t adapt_low16,
+                                                                     const uint32_t stream_out)
 {
     constexpr int WAVES = THREADS / 64;
     constexpr int RADIX = 256;
@@ -1443,7 +1444,24 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
     };
     // the sorted stage over [start, start + cnt), two slots per lane: one 8-byte store each for keys
     // and payload (a sub-bucket starts at any 4-byte boundary; gfx950 serves the wider store there).
-    // Four slots and 16-byte stores measured 2 % slower.
+    // Four slots and 16-byte stores measured 2 % slower.  stream_out (uniform; the host sets it for
+    // inputs well beyond what the last-level cache holds): the stores are nontemporal -- nobody reads
+    // the sorted sub-bucket soon, and as ordinary stores they push the next sub-buckets' pairs out of
+    // the caches: 0.918 against 0.97-0.997 ms at 2^28 pairs, 1.85 against 1.95 at 2^29; at 2^26 the
+    // ordinary stores are the faster ones, 0.305 against 0.327 ms.
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    auto store2 = [&](uint32_t* p, uint32_t x, uint32_t y) __attribute__((always_inline)) {
+        if (stream_out) {
+            const u32x2 v = {x, y};
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+        } else {
+            *reinterpret_cast<uint2*>(p) = make_uint2(x, y);
+        }
+    };
+    auto store1 = [&](uint32_t* p, uint32_t x) __attribute__((always_inline)) {
+        if (stream_out) __builtin_nontemporal_store(x, p);
+        else *p = x;
+    };
     auto write_out = [&](const uint32_t start, const uint32_t cnt, const uint32_t high) __attribute__((always_inline)) {
         uint32_t* __restrict__ kout = keys + start;
         uint32_t* __restrict__ vout = vals + start;
@@ -1452,21 +1470,21 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
                 const uint32_t kk = *reinterpret_cast<const uint32_t*>(&s_key16[s2]);  // s2 is even: two keys in one word
                 if (s2 + 1 < cnt) {
                     const uint2 vv = *reinterpret_cast<const uint2*>(&s_val[s2]);
-                    *reinterpret_cast<uint2*>(kout + s2) = make_uint2(high | (kk & 0xFFFFu), high | (kk >> 16));
-                    *reinterpret_cast<uint2*>(vout + s2) = vv;
+                    store2(kout + s2, high | (kk & 0xFFFFu), high | (kk >> 16));
+                    store2(vout + s2, vv.x, vv.y);
                 } else {
-                    kout[s2] = high | (kk & 0xFFFFu);
-                    vout[s2] = s_val[s2];
+                    store1(kout + s2, high | (kk & 0xFFFFu));
+                    store1(vout + s2, s_val[s2]);
                 }
             } else {
                 if (s2 + 1 < cnt) {
                     const uint4 q = *reinterpret_cast<const uint4*>(&s_pair[s2]);
-                    *reinterpret_cast<uint2*>(kout + s2) = make_uint2(q.x, q.z);
-                    *reinterpret_cast<uint2*>(vout + s2) = make_uint2(q.y, q.w);
+                    store2(kout + s2, q.x, q.z);
+                    store2(vout + s2, q.y, q.w);
                 } else {
                     const uint2 kv = s_pair[s2];
-                    kout[s2] = kv.x;
-                    vout[s2] = kv.y;
+                    store1(kout + s2, kv.x);
+                    store1(vout + s2, kv.y);
                 }
             }
         }
@@ -1678,8 +1696,9 @@ int hybrid_launch_big_histogram(const uint32_t* keys, HybridTables* tables, Hybr
 
 int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,
                              uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, uint32_t key_shift,
-                             bool compact_ok, uint32_t adapt_low16, int grid, hipStream_t s, bool big)
+                             bool compact_ok, uint32_t adapt_low16, int grid, hipStream_t s, bool big, bool stream_out)
 {
+    const uint32_t so = stream_out ? 1u : 0u;
     if (big && (!compact_ok || adapt_low16 != 0u))
         return fail(MRS_ERR_UNSUPPORTED, "the 1024-thread local sort stages 6 bytes per pair and serves the fixed split only");
     if (adapt_low16 != 0u && (adapt_low16 < 16u || (compact_ok && adapt_low16 != 16u)))
@@ -1691,13 +1710,13 @@ int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader*
     const ProfilerRange range("Local sort");
     if (big)
         hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreadsBig, kHybLocalKptCompact, true>), dim3(grid), dim3(kHybLocalThreadsBig),
-                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift, adapt_low16);
+                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift, adapt_low16, so);
     else if (compact_ok)
         hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreads, kHybLocalKptCompact, true>), dim3(grid), dim3(kHybLocalThreads),
-                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift, adapt_low16);
+                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift, adapt_low16, so);
     else
         hipLaunchKernelGGL((hybrid_local_sort_kernel<kHybLocalThreads, kHybLocalKptFull, false>), dim3(grid), dim3(kHybLocalThreads),
-                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift, adapt_low16);
+                           0, s, keys, vals, hdr, tables, shift, bits1, bits2, num_subs, key_shift, adapt_low16, so);
     MRS_CHECK_LAUNCH("hybrid_local_sort_kernel");
     return MRS_OK;
 }

@@ -226,9 +226,12 @@ int hybrid_launch_big_histogram(const uint32_t* keys, HybridTables* tables, Hybr
 // above the sorted range vary).  adapt_low16: 0, or the adaptive schedule is offered and its groups
 // (65536 table entries) are sorted on the two 8-bit digits below bit adapt_low16.
 // big: the workgroups of 1024 threads that hold kHybLocalCapBig pairs (6-byte staging only).
+// stream_out: the sorted sub-buckets are written with nontemporal stores (inputs far larger than the
+// last-level cache).
 int hybrid_launch_local_sort(uint32_t* keys, uint32_t* vals, const HybridHeader* hdr, const HybridTables* tables,
                              uint32_t shift, uint32_t bits1, uint32_t bits2, uint32_t num_subs, uint32_t key_shift,
-                             bool compact_ok, uint32_t adapt_low16, int grid, hipStream_t s, bool big = false);
+                             bool compact_ok, uint32_t adapt_low16, int grid, hipStream_t s, bool big = false,
+                             bool stream_out = false);
 
 }  // namespace mrs
 
