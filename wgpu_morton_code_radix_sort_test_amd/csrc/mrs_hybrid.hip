@@ -1330,8 +1330,13 @@ __global__ __launch_bounds__(THREADS, 4) void hybrid_local_sort_kernel(uint32_t*
         for (int i = 0; i < KU; ++i) {
             const uint32_t e = element(per, i);
             const uint32_t ec = (static_cast<uint32_t>(i) < per && e < count) ? e : 0u;
+#ifdef MRS_LOCAL_NT_LOAD  // A/B builds
+            key[i] = __builtin_nontemporal_load(kin + ec);
+            val[i] = __builtin_nontemporal_load(vin + ec);
+#else
             key[i] = kin[ec];  // nontemporal loads measured 7 % slower
             val[i] = vin[ec];
+#endif
         }
     };
     // sorts the `cnt` pairs held in (key, val) into the stage; returns the key bits every key of the
