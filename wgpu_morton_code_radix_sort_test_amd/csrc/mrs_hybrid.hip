@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void hybrid_reduce_kernel(const uint32_t* __re
 {
     __shared__ uint32_t s_part[4][64][2];
     const uint32_t lane = threadIdx.x & 63u, part = threadIdx.x >> 6;
-    const uint32_t j = blockIdx.x * 64u + lane;  // < kHybPackedWords: the grid is exact
+    const uint32_t j = blockIdx.x * 64u + lane;  // < kHybPackedWords: the grid covers the entries in use, exactly
     uint32_t lo = 0, hi = 0;
     int g = static_cast<int>(part);
     for (; g + 12 < grid; g += 16) {
@@ -310,11 +310,15 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
     HybridHeader* hdr = &hc->hdr;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t c[64];
+    // the split uses the first 2^msd_bits entries of the table; the rest is zero and is neither read
+    // nor (below) given a start, except the one entry behind the last sub-bucket
+    const uint32_t used = 1u << adapt.msd_bits;
     {
         const uint4* c4 = reinterpret_cast<const uint4*>(tb->counts) + tid * 16;
+        const bool live = tid * 64u < used;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const uint4 x = c4[q];
+            const uint4 x = live ? c4[q] : make_uint4(0u, 0u, 0u, 0u);
             c[4 * q] = x.x; c[4 * q + 1] = x.y; c[4 * q + 2] = x.z; c[4 * q + 3] = x.w;
         }
     }
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
     const uint32_t tpb = sub_bits - 6u;  // log2(threads per bucket)
     if ((tid & ((1u << tpb) - 1u)) == 0 && (tid >> tpb) <= kHybBuckets) s_bstart[tid >> tpb] = run;
     if (tid == 1023 && (1024u >> tpb) <= kHybBuckets) s_bstart[1024u >> tpb] = run + sum;  // sub_bits == 8: no thread starts "bucket 256"
-    {
+    if (tid * 64u <= used) {
         uint4* o4 = reinterpret_cast<uint4*>(tb->sub_start) + tid * 16;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -380,8 +384,10 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
             o.w = run; run += c[4 * q + 3];
             o4[q] = o;
         }
-        if (tid == 1023) tb->sub_start[kHybSubs] = run;
+    } else {
+        run += sum;  // (zero: the thread holds no pairs)
     }
+    if (tid == 1023) tb->sub_start[kHybSubs] = run;
     // the oversized sub-buckets, in key order (rare: a second walk over the thread's counts)
     if (nbig != 0u) {
         uint32_t at = run - sum;
@@ -1581,7 +1587,9 @@ int hybrid_launch_scan(const uint32_t* packed, int grid, HybridTables* tables, H
     od.mask3 = (1u << (end_bit - begin_bit - 24u)) - 1u;
     od.window_base = window_base;
     const ProfilerRange range("Small Prefix Sum");  // src/main.rs:625
-    hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(kHybPackedWords / 64), dim3(256), 0, s, packed, grid, hc->spill, tables->counts);
+    // (only the 2^msd_bits entries the split uses: a workgroup adds up 128 of them)
+    if (adapt.msd_bits < 14u || adapt.msd_bits > 16u) return fail(MRS_ERR_INVALID_ARGUMENT, "the exact table has 2^14 to 2^16 entries");
+    hipLaunchKernelGGL(hybrid_reduce_kernel, dim3((1u << adapt.msd_bits) / 128u), dim3(256), 0, s, packed, grid, hc->spill, tables->counts);
     MRS_CHECK_LAUNCH("hybrid_reduce_kernel");
     hipLaunchKernelGGL(hybrid_scan_kernel, dim3(1), dim3(1024), 0, s, tables, hc, n, tile_items, force_mode, sub_bits,
                        compact_ok ? 1u : 0u, cap, adapt, od);
