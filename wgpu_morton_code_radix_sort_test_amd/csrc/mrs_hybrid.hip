@@ -58,9 +58,12 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
     __shared__ int s_diff;
     __shared__ uint32_t s_flags;  // bit 0: a key outside the window, bit 1: bits at or above end_bit differ
     const uint32_t tid = threadIdx.x;
+    // counters beyond 2^bits are never touched: they are neither cleared, nor written out, nor read by
+    // the kernels that follow
+    const uint32_t words4 = (1u << bits) / 8u;  // 16-byte groups of packed words in use (bits >= 14)
     {
         uint4* z = reinterpret_cast<uint4*>(s_cnt);
-        for (uint32_t j = tid; j < kHybPackedWords / 4; j += THREADS) z[j] = make_uint4(0, 0, 0, 0);
+        for (uint32_t j = tid; j < words4; j += THREADS) z[j] = make_uint4(0, 0, 0, 0);
     }
     for (uint32_t j = tid; j < 2 * 256 * kLowCopies; j += THREADS) (&s_low[0][0])[j] = 0;
     if (tid == 0) {
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
     {
         const uint4* c = reinterpret_cast<const uint4*>(s_cnt);
         uint4* out = reinterpret_cast<uint4*>(packed + static_cast<size_t>(blockIdx.x) * kHybPackedWords);
-        for (uint32_t j = tid; j < kHybPackedWords / 4; j += THREADS) {
+        for (uint32_t j = tid; j < words4; j += THREADS) {
             const uint4 w = c[j];
             out[j] = w;
             fields += (w.x & 0xFFFFu) + (w.x >> 16) + (w.y & 0xFFFFu) + (w.y >> 16) + (w.z & 0xFFFFu) + (w.z >> 16) +
@@ -1558,6 +1561,7 @@ int hybrid_launch_histogram(const uint32_t* keys, uint32_t n, uint32_t shift, ui
                             uint32_t* low_hist, hipStream_t s)
 {
     if (shift > begin_bit + 16u) return fail(MRS_ERR_UNSUPPORTED, "the exact table must start within 16 bits of begin_bit");
+    if (bits < 14u || bits > 16u) return fail(MRS_ERR_INVALID_ARGUMENT, "the exact table has 2^14 to 2^16 entries");
     const ProfilerRange range("Histogram calculation");  // src/main.rs:597
     const uint32_t vectors = (reinterpret_cast<uintptr_t>(keys) & 15u) ? 0u : n / 4u;
     hipLaunchKernelGGL(hybrid_histogram_kernel, dim3(grid), dim3(1024), 0, s, keys, n, vectors, shift, bits, packed, hc,
