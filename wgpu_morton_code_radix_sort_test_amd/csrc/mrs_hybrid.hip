@@ -126,6 +126,15 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
     };
     // keys that crowd on few sub-buckets: the lanes that hold the first lane's sub-bucket share one add
     auto count_grouped = [&](uint32_t k) __attribute__((always_inline)) {
+        const uint32_t b = sub_bucket(k);
+        const uint32_t b0 = __builtin_amdgcn_readfirstlane(b);
+        const unsigned long long same = __builtin_amdgcn_uicmp(b, b0, 32 /* == */);  // among the active lanes
+        const uint32_t group = static_cast<uint32_t>(__popcll(same));
+        if (group < 8u) {  // uniform: this instruction's keys are spread after all
+            count_low(k, 1u);
+            add_field(b, 1u);
+            return;
+        }
         {
             // equal keys share their low digits too: one lane counts for the lanes that hold the
             // first lane's 16 low bits
@@ -139,11 +148,7 @@ __global__ __launch_bounds__(1024) void hybrid_histogram_kernel(const uint32_t* 
                 count_low(k, 1u);
             }
         }
-        const uint32_t b = sub_bucket(k);
-        const uint32_t b0 = __builtin_amdgcn_readfirstlane(b);
-        const unsigned long long same = __builtin_amdgcn_uicmp(b, b0, 32 /* == */);  // among the active lanes
-        const uint32_t group = static_cast<uint32_t>(__popcll(same));
-        if (group >= 8u && b == b0) {
+        if (b == b0) {
             if (lanes_below(static_cast<uint32_t>(same), static_cast<uint32_t>(same >> 32)) == 0u) add_field(b0, group);
         } else {
             add_field(b, 1u);
