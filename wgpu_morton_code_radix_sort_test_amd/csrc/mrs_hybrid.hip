@@ -399,7 +399,7 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
     // the oversized sub-buckets, in key order (rare: a second walk over the thread's counts)
     if (nbig != 0u) {
         uint32_t at = run - sum;
-#pragma unroll 1
+#pragma unroll  // (a loop that indexes c[] at run time would move the whole array to scratch memory, for every access)
         for (int q = 0; q < 64; ++q) {
             if (c[q] > cap) {
                 if (bigoff < kHybMaxBig) {
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(1024) void hybrid_scan_kernel(HybridTables* tb, Hyb
         const uint32_t first = tid * 64u + od.window_base;
         uint32_t run2 = (first >> od.shift2) & od.mask2, sum2 = 0;
         uint32_t run3 = (first >> od.shift3) & od.mask3, sum3 = 0;
-#pragma unroll 1
+#pragma unroll
         for (int q = 0; q < 64; ++q) {
             const uint32_t at = first + static_cast<uint32_t>(q);
             const uint32_t d2 = (at >> od.shift2) & od.mask2, d3 = (at >> od.shift3) & od.mask3;
