@@ -52,7 +52,8 @@ def rank_keys(oracle, n, key_words, dist, seed, end_bit):
     return k.reshape(-1)
 
 
-def run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, tolerance, rounds=1, chunks=0, hybrid_min_n=0):
+def run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, tolerance, rounds=1, chunks=0, hybrid_min_n=0,
+              big_local=False):
     """One thread per rank on GPU 0; returns per-rank (keys, payload) numpy arrays and infos."""
     from wgpu_morton_code_radix_sort_test_amd.dist import Communicator, DistributedSorter
 
@@ -65,6 +66,8 @@ def run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, tolerance, round
             torch.cuda.set_device(0)
             ctx = mrs.Context(0)
             ctx.set_attribute(ctx.ATTR_TEST_HYBRID_MIN_N, hybrid_min_n)  # read by the plans the handle creates
+            if big_local:
+                ctx.set_attribute(ctx.ATTR_TEST_HYBRID_BIG_LOCAL, 1)
             stream = torch.cuda.Stream()
             n = sizes[r]
             with torch.cuda.stream(stream):
@@ -198,6 +201,24 @@ def test_local_sorts_take_the_three_move_schedule(oracle, mrs, world, end_bit, d
     seen = {int(i.last_sort_schedule[c]) for i in infos for c in range(pieces)}
     if want == "msd":
         assert seen == {1}, seen
+
+
+@pytest.mark.parametrize("world,end_bit,dist,chunks", [(2, 30, "morton30", 0), (2, 30, "morton30", 1), (4, 32, "random", 2),
+                                                       (8, 32, "hot_bucket", 0), (3, 28, "few_values", 0)])
+def test_local_sorts_with_workgroups_of_1024_threads(oracle, mrs, world, end_bit, dist, chunks):
+    """Pieces of about 2^29 pairs (a quarter of 2^31) whose window is a little wider than a quarter of
+    the key space get sub-buckets of about 16384 pairs, which only the local sort's workgroups of 1024
+    threads hold; the test asks for those workgroups at a size the checker can follow."""
+    rng = np.random.default_rng(world * 13 + end_bit)
+    sizes = [int(rng.integers(60000, 200000)) for _ in range(world)]
+    if world == 3:
+        sizes[1] = 0
+    host_keys = [rank_keys(oracle, n, 1, dist, seed=19 * r + 5, end_bit=end_bit) for r, n in enumerate(sizes)]
+    results, infos = run_ranks(mrs, world, sizes, host_keys, 1, end_bit, 0, chunks=chunks, hybrid_min_n=1, big_local=True)
+    check_against_oracle(oracle, results, host_keys, sizes, 1, end_bit, max(sizes) // 256)
+    if dist == "morton30":
+        pieces = chunks or 2
+        assert {int(i.last_sort_schedule[c]) for i in infos for c in range(pieces)} == {1}
 
 
 def test_local_ranks_fuzz(oracle, mrs):

@@ -260,13 +260,15 @@ def _props(keys_in, idx_in, ok, ov):
     assert int(v.sum()) == ok.numel() * (ok.numel() - 1) // 2, "payload is not a permutation"
 
 
-@pytest.mark.parametrize("dist_name", ["morton30", "all_equal", "one_hot_bucket"])
-def test_sharded_sort_one_rccl_rank_full_size(ctx, mrs, dist_name):
+@pytest.mark.parametrize("dist_name,log2n", [("morton30", 28), ("all_equal", 28), ("one_hot_bucket", 28), ("morton30", 29)])
+def test_sharded_sort_one_rccl_rank_full_size(ctx, mrs, dist_name, log2n):
     """mrs_dist_sort_pairs over RCCL with one rank at the per-GPU size of the 8-GPU configuration
-    (2^28 pairs): ncclAllReduce / ncclAllGather of the histogram, grouped self send/receive, local sort."""
+    (2^28 pairs): ncclAllReduce / ncclAllGather of the histogram, grouped self send/receive, local sort.
+    At 2^29 pairs each array of the transfer holds 2 GiB: a single ncclSend of that size lost data, so
+    the transport cuts transfers into operations of at most 1 GiB."""
     from wgpu_morton_code_radix_sort_test_amd.dist import Communicator, DistributedSorter
 
-    n = 1 << 28
+    n = 1 << log2n
     if dist_name == "morton30":
         xyz = ctx.generate_points(5, n)
         keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])

@@ -994,18 +994,24 @@ struct HybridSplit {
 // whose sub-buckets would hold about 5000 pairs or fewer if the keys were spread evenly (a window
 // that is a little wider than a power of two needs the next shift, and with it twice the
 // sub-bucket size) and whose local sort gets at most 16 bits; failing that, the finest split if
-// evenly spread keys would still fit a workgroup with a sixth to spare.  False when there is none
-// (a window too wide for this n, or so narrow that its keys cannot spread) or the window is empty.
-static bool hybrid_window_split(uint32_t begin, uint32_t n, uint64_t lo, uint64_t hi, HybridSplit* out)
+// evenly spread keys would still fit a workgroup with a sixth to spare -- a workgroup of 512
+// threads, or else one of 1024 (twice the pairs; 6-byte staging only: a quarter of 2^31 pairs, whose
+// window is as likely as not a little wider than a quarter of the key space).  `force_big`: test aid,
+// the large workgroups or nothing.  False when there is none (a window too wide for this n, or so
+// narrow that its keys cannot spread) or the window is empty.
+static bool hybrid_window_split(uint32_t begin, uint32_t n, uint64_t lo, uint64_t hi, bool force_big, HybridSplit* out)
 {
     if (hi < lo || hi > 0xFFFFFFFFull) return false;
-    for (uint32_t bits = 14; bits <= 16; ++bits) {
+    for (uint32_t attempt = force_big ? 3u : 0u; attempt < 4u; ++attempt) {
+        const bool big = attempt == 3u;
+        const uint32_t bits = big ? 16u : 14u + attempt;
         uint32_t shift = begin + 2;  // the local sort takes two digits of at least one bit
         while (shift < 32 && ((hi >> shift) - (lo >> shift)) >= (1ull << bits)) ++shift;
         const uint64_t subs = (hi >> shift) - (lo >> shift) + 1;
-        const uint64_t limit = bits < 16 ? hybrid_local_cap(shift) * 4ull / 5 : hybrid_local_cap(shift) * 5ull / 6;
-        if (shift - begin <= 16 && n / subs <= limit) {
-            *out = HybridSplit{bits, shift, static_cast<uint32_t>(lo >> shift), true, false};
+        const uint64_t limit = big ? kHybLocalCapBig * 5ull / 6
+                                   : (bits < 16 ? hybrid_local_cap(shift) * 4ull / 5 : hybrid_local_cap(shift) * 5ull / 6);
+        if (shift - begin <= 16 && (!big || shift <= 16u) && n / subs <= limit) {
+            *out = HybridSplit{bits, shift, static_cast<uint32_t>(lo >> shift), true, big};
             return true;
         }
     }
@@ -1021,7 +1027,7 @@ static bool hybrid_choose_split(uint32_t begin, uint32_t end, uint64_t n, const 
     const uint32_t n32 = static_cast<uint32_t>(n);
     if (window) {
         const uint64_t min_n = aids.hybrid_min_n != 0 ? aids.hybrid_min_n : 3ull << 24;  // slices are never exact powers of two
-        return n >= min_n && hybrid_window_split(begin, n32, window[0], window[1], split);
+        return n >= min_n && hybrid_window_split(begin, n32, window[0], window[1], aids.hybrid_big_local != 0, split);
     }
     // Evenly spread keys must leave sub-buckets a workgroup can hold with a sixth to spare (the few
     // that do not fit are sorted by two extra passes, but not most of them): up to about 2^28.7

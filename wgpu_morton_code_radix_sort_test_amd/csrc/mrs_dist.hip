@@ -145,16 +145,26 @@ struct RcclComm final : mrs_comm {
     {
         // RCCL has no all-to-all-v: one send and one receive per peer and array, fused in a group
         // so that they progress together; every peer pair has its own xGMI link.
+        // A transfer goes out in operations of at most kMaxOpBytes: a send of 2 GiB and more (seen with
+        // a rank's send to itself, RCCL 2.26) delivered part of the data only, without any error.  The
+        // sender and the receiver of a transfer know the same count, so both cut it alike, and
+        // operations between one pair of ranks match in the order they were posted.
+        constexpr size_t kMaxOpBytes = size_t(1) << 30;
         MRS_NCCL_TRY(api, api->GroupStart());
         for (int a = 0; a < x.count; ++a) {
             const size_t eb = x.elem_bytes[a];
+            const uint64_t step = kMaxOpBytes / eb;  // elements per operation
             for (int p = 0; p < world; ++p) {
-                if (send_cnt[p])
-                    MRS_NCCL_TRY(api, api->Send(static_cast<const char*>(x.send[a]) + send_off[p] * eb, send_cnt[p] * eb,
+                for (uint64_t at = 0; at < send_cnt[p]; at += step) {
+                    const uint64_t cnt = send_cnt[p] - at < step ? send_cnt[p] - at : step;
+                    MRS_NCCL_TRY(api, api->Send(static_cast<const char*>(x.send[a]) + (send_off[p] + at) * eb, cnt * eb,
                                                 ncclUint8, p, comm, s));
-                if (recv_cnt[p])
-                    MRS_NCCL_TRY(api, api->Recv(static_cast<char*>(x.recv[a]) + recv_off[p] * eb, recv_cnt[p] * eb,
+                }
+                for (uint64_t at = 0; at < recv_cnt[p]; at += step) {
+                    const uint64_t cnt = recv_cnt[p] - at < step ? recv_cnt[p] - at : step;
+                    MRS_NCCL_TRY(api, api->Recv(static_cast<char*>(x.recv[a]) + (recv_off[p] + at) * eb, cnt * eb,
                                                 ncclUint8, p, comm, s));
+                }
             }
         }
         MRS_NCCL_TRY(api, api->GroupEnd());

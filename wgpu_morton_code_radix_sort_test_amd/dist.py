@@ -67,6 +67,9 @@ def _as_tensor(ptr, words, device):
     return torch.as_tensor(_DeviceView(ptr, words), device=device)
 
 
+_SCHEDULE_NAMES = {0: "passes", 1: "msd", 2: "msd refused by the device", 3: "msd adaptive"}
+
+
 class DistributedSorter:
     """`mrs_dist`: rank `comm.rank`'s end of the sharded sort of (key, payload) pairs."""
 
@@ -136,8 +139,7 @@ class DistributedSorter:
             "dist_local_sort_pass_ms": float(i.last_sort_pass_ms),
             "dist_local_sort_passes": int(i.last_sort_passes),
             "dist_local_sort_piece_pairs": int(i.last_sort_piece_pairs),
-            "dist_local_sort_schedule": [{0: "passes", 1: "msd", 2: "msd refused by the device"}[int(x)]
-                                         for x in i.last_sort_schedule],
+            "dist_local_sort_schedule": [_SCHEDULE_NAMES.get(int(x), str(int(x))) for x in i.last_sort_schedule],
         }
 
 
