@@ -212,7 +212,9 @@ int mrs_plan_get_passes_left_out(mrs_plan* plan, void* stream, uint32_t* left_ou
  * host's decision (n too small or too large for sub-buckets of a workgroup's size, or no split of
  * the window leaves the local sort 16 bits or fewer).  Otherwise the two scatters take
  * leading_bits (14..16) bits from bit `shift` up -- of the key, or, windowed, of
- * (key >> shift) - base -- and the sort inside LDS the local_bits bits [begin_bit, shift).  The
+ * (key >> shift) - base -- and the sort inside LDS the local_bits bits [begin_bit, shift), in
+ * workgroups that hold local_capacity pairs (7680 staged in 8 bytes each; 10240, or 20480 in the
+ * workgroups of 1024 threads that the largest inputs take, staged in 6).  The
  * device still has the last word at run time (see mrs_plan_get_schedule, mrs_plan_get_oversized). */
 typedef struct mrs_hybrid_split {
     int32_t offered;
@@ -221,6 +223,7 @@ typedef struct mrs_hybrid_split {
     uint32_t shift;
     uint32_t base;
     uint32_t local_bits;
+    uint32_t local_capacity; /* pairs a workgroup of the local sort holds: 7680, 10240 or 20480 */
 } mrs_hybrid_split;
 int mrs_hybrid_split_for(uint64_t n, int32_t begin_bit, int32_t end_bit, const uint64_t* window,
                          mrs_hybrid_split* out);

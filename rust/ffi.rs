@@ -49,6 +49,7 @@ pub struct mrs_hybrid_split {
     pub shift: u32,
     pub base: u32,
     pub local_bits: u32,
+    pub local_capacity: u32,
 }
 
 #[repr(C)]

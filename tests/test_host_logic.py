@@ -208,6 +208,8 @@ def test_hybrid_split_of_the_whole_key_space():
             # ... and 20480 in the workgroups of 1024 threads that larger inputs take where 6-byte staging applies
             cap = 10240 if s.shift <= 16 else 7680
             largest = 20480 if s.shift <= 16 else 7680
+            if s.offered:
+                assert s.local_capacity == (cap if (n >> s.leading_bits) <= cap * 5 // 6 else largest)
             assert bool(s.offered) == (min_n <= n and (n >> s.leading_bits) <= largest * 5 // 6), (begin, end, n)
             if s.offered:
                 assert n / (1 << s.leading_bits) <= largest * 5 // 6 + 1
@@ -226,11 +228,11 @@ def test_hybrid_split_of_a_window():
     or fewer in each, and the local sort must get 16 bits or fewer."""
     lib = _lib.load_library()
     rng = np.random.RandomState(5)
-    offered = 0
+    offered = big = 0
     for case in range(4000):
         end = int(rng.choice([30, 32]))
         top = (1 << end) - 1
-        n = int(rng.choice([3 << 24, 1 << 26, (1 << 26) + 777, 1 << 27, 1 << 28, 5 << 26]))
+        n = int(rng.choice([3 << 24, 1 << 26, (1 << 26) + 777, 1 << 27, 1 << 28, 5 << 26, (1 << 29) - 4000]))
         parts = int(rng.choice([2, 4, 8, 16]))
         v = int(rng.randint(parts))
         width = (top + 1) // parts
@@ -251,8 +253,17 @@ def test_hybrid_split_of_a_window():
         # four fifths of what a workgroup holds (10240 pairs staged in 6 bytes each when the sub-bucket's
         # own bits start at bit 16 or below, else 7680), or with the finest split all but a sixth of it
         cap = 10240 if s.shift <= 16 else 7680
-        assert n // subs <= (cap * 4 // 5 if s.leading_bits < 16 else cap * 5 // 6)
-    assert offered > 2000
+        if s.local_capacity == 20480:
+            # the last resort, the workgroups of 1024 threads: no split fits the smaller ones
+            big += 1
+            assert s.leading_bits == 16 and s.shift <= 16 and cap * 5 // 6 < n // subs <= 20480 * 5 // 6
+        else:
+            assert s.local_capacity == cap
+            assert n // subs <= (cap * 4 // 5 if s.leading_bits < 16 else cap * 5 // 6)
+    assert offered > 2000 and big > 0
+    # a quarter of 2^31 pairs whose window is a little wider than a quarter of 30 bits
+    s = _hybrid_split(lib, (1 << 29) + 5000, 0, 30, (1 << 28, (1 << 29) + 4096))[1]
+    assert s.offered and s.local_capacity == 20480 and s.shift == 13 and s.leading_bits == 16
     # a window so narrow that its keys cannot spread is not offered; nor is one too wide for n
     assert not _hybrid_split(lib, 1 << 27, 0, 32, (12345, 12345))[1].offered
     assert not _hybrid_split(lib, 1 << 20, 0, 32, (0, (1 << 32) - 1))[1].offered

@@ -60,6 +60,7 @@ class HybridSplit(ctypes.Structure):
         ("shift", ctypes.c_uint32),
         ("base", ctypes.c_uint32),
         ("local_bits", ctypes.c_uint32),
+        ("local_capacity", ctypes.c_uint32),
     ]
 
 

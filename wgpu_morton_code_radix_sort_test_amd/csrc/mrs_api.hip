@@ -1397,6 +1397,7 @@ extern "C" int mrs_hybrid_split_for(uint64_t n, int32_t begin_bit, int32_t end_b
     out->base = split.base;
     out->windowed = split.windowed ? 1 : 0;
     out->local_bits = split.shift - begin_bit;
+    out->local_capacity = split.big ? kHybLocalCapBig : hybrid_local_cap(split.shift);
     return MRS_OK;
 }
 
