@@ -58,9 +58,21 @@ def one(ctx, n, dist, begin_bit, end_bit, indexed=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also 2^26 and 2^28 pairs")
+    ap.add_argument("--sizes", type=int, nargs="*", default=[],
+                    help="only these element counts: 30-bit codes on bits [0, 30), random keys on [0, 32) and [0, 28)")
     args = ap.parse_args()
     ctx = mrs.Context(0)
     ok = True
+    if args.sizes:
+        for n in args.sizes:
+            ok &= one(ctx, n, "morton30", 0, 30)
+            torch.cuda.empty_cache()
+            ok &= one(ctx, n, "random", 0, 32, indexed=True)
+            torch.cuda.empty_cache()
+            ok &= one(ctx, n, "random", 0, 28)
+            torch.cuda.empty_cache()
+        print("ALL OK" if ok else "FAILURES")
+        return 0 if ok else 1
     sizes = [4097, 5000, 65536, 100003, (1 << 20) + 123, (1 << 22) + 7]
     for n in sizes:
         for dist in ("morton30", "random", "equal", "fewvalues", "onebucket"):
