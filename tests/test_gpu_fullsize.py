@@ -194,6 +194,43 @@ def test_full_size_uneven_keys(ctx, mrs, log2n, shape, want):
     plan.close()
 
 
+@pytest.mark.parametrize("algo_name,mask", [("onesweep", 0x3FFFFFF), ("three_kernel", -1)])
+def test_largest_supported_sort(ctx, mrs, algo_name, mask):
+    """2^32 - 2 (key, source index) pairs, the most a plan takes: element numbers and byte offsets
+    beyond 2^31 and 2^34 (64-bit tile status words and offsets).  Checked in slices of 2^28 elements:
+    ascending keys, ties in index order (26-bit keys: 64 of each), every index pointing at its key,
+    and the index sum of a permutation."""
+    n = (1 << 32) - 2
+    torch.cuda.empty_cache()  # the plan allocates beside torch's cache
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 24 * n:
+        pytest.skip("not enough free device memory for 2^32 pairs")
+    algo = {"onesweep": mrs.ALGO_ONESWEEP, "three_kernel": mrs.ALGO_THREE_KERNEL}[algo_name]
+    keys = ctx.generate_u32(9, 1, n)
+    if mask >= 0:
+        keys &= mask
+    ka, va = keys.clone(), torch.empty(n, dtype=torch.int32, device=ctx.device)
+    kb, vb = torch.empty_like(ka), torch.empty_like(va)
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, algo=algo)
+    in_b = plan.sort_pairs_indexed(ka, va, kb, vb)
+    plan.check()
+    ok, ov = (kb, vb) if in_b else (ka, va)
+    step, prev, index_sum = 1 << 28, None, 0
+    for at in range(0, n, step):
+        k = ok[at:at + step].to(torch.int64) & 0xFFFFFFFF
+        v = ov[at:at + step].to(torch.int64) & 0xFFFFFFFF
+        dk = k[1:] - k[:-1]
+        assert bool(((dk > 0) | ((dk == 0) & (v[1:] > v[:-1]))).all()), f"order breaks inside slice {at >> 28}"
+        first = (int(k[0]), int(v[0]))
+        assert prev is None or prev < first, f"order breaks before slice {at >> 28}"
+        prev = (int(k[-1]), int(v[-1]))
+        assert bool(((keys[v].to(torch.int64) & 0xFFFFFFFF) == k).all()), "an index does not point at its key"
+        index_sum += int(v.sum())
+        del k, v, dk
+    assert index_sum == n * (n - 1) // 2
+    plan.close()
+
+
 @pytest.mark.parametrize("payload_words", [1, 4])
 def test_large_u64_keys_properties(ctx, mrs, payload_words):
     """64-bit keys (the reference's code type) with an index or a 16-byte TriangleIndices-sized
