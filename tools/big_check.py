@@ -38,8 +38,30 @@ def check(keys_in, ok, ov, n):
     return good and total_in == total_out
 
 
+def check64(words_in, ok, ov, n):
+    """The same for 64-bit keys (two words each, the high word second)."""
+    good, prev, index_sum = True, None, 0
+    for at in range(0, n, STEP):
+        end = min(n, at + STEP)
+        w = ok[2 * at:2 * end].view(-1, 2)
+        kl, kh, v = u(w[:, 0]), u(w[:, 1]), u(ov[at:end])
+        up = kh[1:] > kh[:-1]
+        same_h = kh[1:] == kh[:-1]
+        good &= bool((up | (same_h & (kl[1:] > kl[:-1])) | (same_h & (kl[1:] == kl[:-1]) & (v[1:] > v[:-1]))).all())
+        first = (int(kh[0]), int(kl[0]), int(v[0]))
+        if prev is not None:
+            good &= prev < first
+        prev = (int(kh[-1]), int(kl[-1]), int(v[-1]))
+        src = words_in.view(-1, 2)[v]
+        good &= bool((u(src[:, 0]) == kl).all() and (u(src[:, 1]) == kh).all())
+        index_sum += int(v.sum())
+        del w, kl, kh, v, up, same_h, src
+    return good and index_sum == n * (n - 1) // 2
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--key-words", type=int, default=1)
     ap.add_argument("--n", type=int, nargs="+", default=[3 << 30, (1 << 32) - 2])
     ap.add_argument("--algo", default="onesweep")
     ap.add_argument("--mask", type=lambda x: int(x, 0), default=0xFFFFFFFF, help="AND mask on the random keys")
@@ -48,17 +70,17 @@ def main():
     algo = {"onesweep": mrs.ALGO_ONESWEEP, "three_kernel": mrs.ALGO_THREE_KERNEL}[args.algo]
     bad = False
     for n in args.n:
-        keys = ctx.generate_u32(9, 1, n)
+        keys = ctx.generate_u32(9, 1, n * args.key_words)
         if args.mask != 0xFFFFFFFF:
             keys &= args.mask - (1 << 32) if args.mask >= (1 << 31) else args.mask
         ka, va = keys.clone(), torch.empty(n, dtype=torch.int32, device=ctx.device)
         kb, vb = torch.empty_like(ka), torch.empty_like(va)
-        plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, algo=algo)
+        plan = mrs.SortPlan(ctx, n, key_words=args.key_words, payload_bytes=4, digit_bits=8, algo=algo)
         in_b = plan.sort_pairs_indexed(ka, va, kb, vb)
         plan.check()
         torch.cuda.synchronize()
         rk, rv = (kb, vb) if in_b else (ka, va)
-        good = check(keys, rk, rv, n)
+        good = check(keys, rk, rv, n) if args.key_words == 1 else check64(keys, rk, rv, n)
         print(f"n = {n}: {'ok' if good else 'MISMATCH'}", flush=True)
         bad |= not good
         plan.close()
