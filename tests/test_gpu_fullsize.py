@@ -231,6 +231,42 @@ def test_largest_supported_sort(ctx, mrs, algo_name, mask):
     plan.close()
 
 
+@pytest.mark.parametrize("log2n,record_words,algo_name", [(28, 4, "hybrid"), (26, 16, "hybrid"), (27, 9, "onesweep")])
+def test_full_size_sort_gather(ctx, mrs, log2n, record_words, algo_name):
+    """mrs_sort_gather at the metric's size: (30-bit code, source index) pairs sorted by the plan, then
+    every record (16, 64 or 36 bytes) moved once.  Word 0 of a record is its source index and word 1
+    its key, the rest a function of the index, so the output tells whether every record arrived
+    whole, behind its key, in index order among equal keys."""
+    n = 1 << log2n
+    torch.cuda.empty_cache()
+    xyz = ctx.generate_points(21, n)
+    keys, idx = ctx.morton_encode30(xyz, [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+    del xyz
+    recs = torch.empty((n, record_words), dtype=torch.int32, device=ctx.device)
+    recs[:, 0] = idx
+    recs[:, 1] = keys
+    for w in range(2, record_words):
+        recs[:, w] = idx * (2 * w + 1) + w
+    algo = {"hybrid": mrs.ALGO_HYBRID, "onesweep": mrs.ALGO_ONESWEEP}[algo_name]
+    plan = mrs.SortPlan(ctx, n, key_words=1, payload_bytes=4, digit_bits=8, end_bit=30, algo=algo)
+    ka, kb = keys.clone(), torch.empty_like(keys)
+    rout = torch.empty_like(recs)
+    in_b, index = plan.sort_gather(ka, kb, recs, rout, 4 * record_words)
+    plan.check()
+    ok = kb if in_b else ka
+    k = ok.to(torch.int64)
+    v = rout[:, 0].to(torch.int64)
+    dk = k[1:] - k[:-1]
+    assert bool(((dk > 0) | ((dk == 0) & (v[1:] > v[:-1]))).all()), "order or stability"
+    assert torch.equal(rout[:, 1], ok), "a record is not behind its key"
+    assert torch.equal(index[:n], rout[:, 0]), "the sorted source indices differ from the records'"
+    assert int(v.sum()) == n * (n - 1) // 2
+    for w in range(2, record_words):
+        assert torch.equal(rout[:, w], rout[:, 0] * (2 * w + 1) + w), f"word {w} of a record was torn"
+    assert torch.equal(keys[v], ok)
+    plan.close()
+
+
 @pytest.mark.parametrize("payload_words", [1, 4])
 def test_large_u64_keys_properties(ctx, mrs, payload_words):
     """64-bit keys (the reference's code type) with an index or a 16-byte TriangleIndices-sized
