@@ -95,6 +95,7 @@ struct State {
     Buffers buffers;
     std::vector<uint8_t> uniforms, verts, tris;  // this frame's uploads (alive while the stream reads them)
     uint64_t frames = 0;
+    void* frame_start = nullptr;  // hipEvent_t, optional: recorded when the frame's scene is ready and its uploads begin
     int init(const Constants& constants);
     int render();
     void destroy();
@@ -112,7 +113,8 @@ struct HeadlessResult {
 int run_headless(const Constants& c, HeadlessResult* res, bool verbose);
 // `frames` calls of State::render on one State, then the checks of run_headless on the last frame;
 // *ms_per_frame = wall time per frame (scene generation on the CPU included, as in the reference's loop),
-// *device_ms_per_frame = HIP-event time of the enqueued work per frame.
+// *device_ms_per_frame = HIP-event time of the enqueued work per frame (uploads from pageable host memory,
+// encode, sort), the first of several frames left out (it loads the kernels).
 int run_frames(const Constants& c, uint32_t frames, HeadlessResult* res, double* ms_per_frame, double* device_ms_per_frame);
 
 }  // namespace mrs_host
