@@ -84,6 +84,8 @@ int run_compute_shaders(mrs_context* ctx, void* stream, const Constants& c, Buff
 int create_all_buffers(mrs_context* ctx, const Constants& c, Buffers* out);
 int record_frame(mrs_context* ctx, void* stream, const Constants& c, const std::vector<uint8_t>& uniforms,
                  const std::vector<uint8_t>& verts, const std::vector<uint8_t>& tris, Buffers* b);
+int record_frame(mrs_context* ctx, void* stream, const Constants& c, const void* uniforms, size_t uniforms_bytes,
+                 const void* verts, size_t verts_bytes, const void* tris, size_t tris_bytes, Buffers* b);
 
 // Counterpart of the reference's State (src/state.rs:14-22, 24-87, 109-148): init() once, render()
 // per frame.  Unlike the reference's render(), which calls run_compute_shaders and with it
@@ -93,7 +95,8 @@ struct State {
     void* stream = nullptr;  // hipStream_t
     Constants c;
     Buffers buffers;
-    std::vector<uint8_t> uniforms, verts, tris;  // this frame's uploads (alive while the stream reads them)
+    void* staging = nullptr;  // page-locked: this frame's uploads (uniforms, vertices, triangles), alive while the stream reads them
+    size_t staging_bytes = 0;
     uint64_t frames = 0;
     void* frame_start = nullptr;  // hipEvent_t, optional: recorded when the frame's scene is ready and its uploads begin
     int init(const Constants& constants);
