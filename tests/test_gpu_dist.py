@@ -225,7 +225,8 @@ def test_local_ranks_fuzz(oracle, mrs):
     """Seeded random shapes of the sharded sort: rank count, slice sizes (empty and tiny slices
     included), key width and live bits, distribution, tolerance and pieces per rank drawn together.
     MRS_DIST_FUZZ_CASES / MRS_DIST_FUZZ_SEED widen a run; MRS_DIST_FUZZ_HYBRID_MIN_N=1 lets the local sorts of
-    these small pieces take the three-move schedule."""
+    these small pieces take the three-move schedule, MRS_DIST_FUZZ_BIG_LOCAL=1 with the local sort's workgroups of
+    1024 threads."""
     import os
 
     rng = np.random.default_rng(int(os.environ.get("MRS_DIST_FUZZ_SEED", "5")))
@@ -246,7 +247,8 @@ def test_local_ranks_fuzz(oracle, mrs):
         what = (case, world, key_words, end_bit, dist, sizes, chunks, tolerance)
         try:
             results, _ = run_ranks(mrs, world, sizes, host_keys, key_words, end_bit, 0 if tolerance is None else tolerance,
-                                   chunks=chunks, hybrid_min_n=int(os.environ.get("MRS_DIST_FUZZ_HYBRID_MIN_N", "0")))
+                                   chunks=chunks, hybrid_min_n=int(os.environ.get("MRS_DIST_FUZZ_HYBRID_MIN_N", "0")),
+                                   big_local=os.environ.get("MRS_DIST_FUZZ_BIG_LOCAL") == "1")
             check_against_oracle(oracle, results, host_keys, sizes, key_words, end_bit, max(tol, 1))
         except AssertionError as exc:
             raise AssertionError(f"{what}: {exc}") from exc
